@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- attention-forward TFLOP/s of the HIP path on MI355X, BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one forward launch over the whole per-GPU batch (B=8,H=16,N=4096,d=64 fp16 in,
+fp32 out: the configuration BASELINE.json's metric is quoted on), inputs resident in HBM.
+For N>1 the driver starts one rank per GPU (torch.distributed.run); every rank runs the same
+per-GPU workload on its own (b,h) shard of a global batch of 8*N (weak scaling, no data-path
+collective -- SURVEY.md 8(e)); the barrier-bracketed wall time is max-reduced over ranks.
+
+Rank 0 prints ONE JSON line with the contract keys plus `roofline` (dominant kernel, HIP events
+on the launch stream) and `cpu_baseline` (the oracle's naive 3-loop fp32 port, timed on this
+host's cores over a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--H", type=int, default=16)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
+    ap.add_argument("--out", choices=["f32", "same"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import flashattention_kernel_project_amd as fa
+    from flashattention_kernel_project_amd.dist import Ranks, timed_region
+
+    fa.lib()   # fail loudly if the HIP library is missing: there is no fallback path
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    ranks = Ranks(backend="nccl" if world > 1 else None)
+    dev = torch.device("cuda", ranks.local_rank)
+    torch.cuda.set_device(dev)
+
+    B, H, N, d = args.B, args.H, args.N, args.d
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    odt = torch.float32 if args.out == "f32" else dt
+    # this rank's shard of the global (B*world) x H problem: B x H heads, generated in place
+    g = torch.Generator(device=dev).manual_seed(42 + ranks.rank)
+    q, k, v = (torch.randn(B, H, N, d, generator=g, device=dev, dtype=torch.float32).to(dt) for _ in range(3))
+    o = torch.empty(B, H, N, d, device=dev, dtype=odt)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        fa.fa_forward(q, k, v, out=o, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def run_steps():
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+
+    wall = timed_region(ranks, run_steps, torch.cuda.synchronize)
+    wall = ranks.max_over_ranks(wall, dev)
+    kern_ms = ev0.elapsed_time(ev1) / args.steps          # avg launch duration, events on the launch stream
+    kern_ms = ranks.max_over_ranks(kern_ms, dev)
+
+    flops_per_gpu = fa.attention_flops(B * H, N, d)
+    total_flops = flops_per_gpu * world * args.steps
+    value = total_flops / wall / 1e12
+    achieved = flops_per_gpu / (kern_ms * 1e-3) / 1e12
+
+    cpu = None
+    if ranks.rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(q, k, v, o, N, d, args.cpu_seconds)
+
+    if ranks.rank == 0:
+        line = {
+            "metric": "attention-fwd TFLOP/s (and %MFMA-peak) at B8 H16 N4096 d64 fp16",
+            "value": round(value, 3),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic N(0,1) Q/K/V rounded to %s, resident in HBM" % args.dtype,
+            "config": {"workload": f"attention forward B={B} H={H} N={N} d={d} per GPU, {args.dtype} in / "
+                                   f"{'fp32' if odt == torch.float32 else args.dtype} out, non-causal, "
+                                   f"global batch {B * world} sharded over (b,h)",
+                       "B_per_gpu": B, "H": H, "N": N, "d": d, "flops_per_step_per_gpu": flops_per_gpu},
+            "pct_mfma_peak": round(100.0 * value / (PEAK_TFLOPS * world), 2),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "fa_fwd_kernel", "avg_launch_ms": round(kern_ms, 5),
+                         "algorithmic_bytes": fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2),
+                         "hbm_GBps_algorithmic": round(fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2)
+                                                       / (kern_ms * 1e-3) / 1e9, 1)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    ranks.close()
+
+
+def cpu_baseline(q, k, v, o_gpu, N, d, budget_s):
+    """The oracle (naive 3-loop fp32 C port of the reference's CPU function) on a bounded sample
+    of the same workload: whole query-row ranges of head (0,0), all N keys, all host cores.
+    Also cross-checks the GPU output on that sample (the oracle is the checker, never the path)."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    qs, ks, vs = (t[0, 0].float().cpu().numpy()[None] for t in (q, k, v))
+    flops_row = 4.0 * N * d
+    t0 = time.perf_counter()
+    orc.forward(qs, ks, vs, accum=0, nthreads=cores, row_range=(0, 2 * cores))
+    cal = max(time.perf_counter() - t0, 1e-4)
+    rows = int(min(N, max(4 * cores, (budget_s / cal) * 2 * cores)))
+    t0 = time.perf_counter()
+    want = orc.forward(qs, ks, vs, accum=0, nthreads=cores, row_range=(0, rows))
+    dt_ = time.perf_counter() - t0
+    err = orc.max_abs(o_gpu[0, 0, :rows].float().cpu().numpy(), want[0, :rows])
+    return {"value": round(rows * flops_row / dt_ / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} query rows x {N} keys of head (b=0,h=0), d={d}, {dt_:.2f} s on {cores} threads "
+                      f"(naive 3-loop fp32, OpenMP over rows)",
+            "gpu_vs_cpu_max_abs_on_sample": float(err)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""ctypes binding of include/fa_mi355.h (libfa_mi355.so, built in-tree by csrc/Makefile)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfa_mi355.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F16, BF16 = 0, 1
+OUT_F32, OUT_SAME = 0, 1
+ALGO_AUTO, ALGO_GENERIC, ALGO_TILED = 0, 1, 2
+
+# every symbol include/fa_mi355.h declares
+SYMBOLS = (
+    "flashattn_forward_wmma",
+    "fa_forward",
+    "fa_forward_ex",
+    "flashattn_streaming_16x16_mw",
+    "flashattn_streaming_16x16_mw_kt",
+    "fa_mi355_version",
+)
+
+
+class FaError(RuntimeError):
+    """A launcher returned a non-zero hipError_t."""
+
+    def __init__(self, fn: str, code: int):
+        super().__init__(f"{fn} failed with hipError_t {code}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile libfa_mi355.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C flashattention_kernel_project_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.flashattn_forward_wmma.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]
+        L.fa_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, vp]
+        L.fa_forward_ex.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, i, vp]
+        L.flashattn_streaming_16x16_mw.argtypes = [vp, vp, vp, vp, i, i, f, vp]
+        L.flashattn_streaming_16x16_mw_kt.argtypes = [vp, vp, vp, vp, i, i, f, vp]
+        for s in SYMBOLS[:-1]:
+            getattr(L, s).restype = C.c_int
+        L.fa_mi355_version.argtypes = []
+        L.fa_mi355_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def version() -> str:
+    return lib().fa_mi355_version().decode()
+
+
+def check(fn: str, code: int) -> None:
+    if code != 0:
+        raise FaError(fn, code)

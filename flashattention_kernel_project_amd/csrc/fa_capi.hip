@@ -1,0 +1,57 @@
+// fa_capi.hip -- extern "C" launchers declared in include/fa_mi355.h.
+#include <hip/hip_runtime.h>
+#include "../../include/fa_mi355.h"
+
+namespace fa {
+hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                            int algo, hipStream_t stream);
+hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
+                                int num_batches, int seq_len, float scale, bool k_transposed,
+                                hipStream_t stream);
+}  // namespace fa
+
+extern "C" {
+
+int flashattn_forward_wmma(const void* Q, const void* K, const void* V, float* O,
+                           int BH, int N, int D, float scale, void* stream)
+{
+    return (int)fa::forward_dispatch(Q, K, V, O, BH, N, D, scale, FA_DTYPE_F16, FA_OUT_F32, FA_ALGO_AUTO,
+                                     static_cast<hipStream_t>(stream));
+}
+
+int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
+                  int B, int H, int N, int d, float scale,
+                  int in_dtype, int out_dtype, int algo, void* stream)
+{
+    if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
+    if (algo < FA_ALGO_AUTO || algo > FA_ALGO_TILED) return (int)hipErrorInvalidValue;
+    if (out_dtype != FA_OUT_F32 && out_dtype != FA_OUT_SAME) return (int)hipErrorInvalidValue;
+    return (int)fa::forward_dispatch(Q, K, V, O, B * H, N, d, scale, in_dtype, out_dtype, algo,
+                                     static_cast<hipStream_t>(stream));
+}
+
+int fa_forward(const void* Q, const void* K, const void* V, void* O,
+               int B, int H, int N, int d, float scale,
+               int in_dtype, int out_dtype, void* stream)
+{
+    return fa_forward_ex(Q, K, V, O, B, H, N, d, scale, in_dtype, out_dtype, FA_ALGO_AUTO, stream);
+}
+
+int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,
+                                 int num_batches, int seq_len, float scale, void* stream)
+{
+    return (int)fa::streaming16_dispatch(Q, K, V, O, num_batches, seq_len, scale, false,
+                                         static_cast<hipStream_t>(stream));
+}
+
+int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, const void* V, float* O,
+                                    int num_batches, int seq_len, float scale, void* stream)
+{
+    return (int)fa::streaming16_dispatch(Q, K_T, V, O, num_batches, seq_len, scale, true,
+                                         static_cast<hipStream_t>(stream));
+}
+
+const char* fa_mi355_version(void) { return "fa_mi355 0.1.0 gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// fa_common.hpp -- shared device helpers for the gfx950 (MI355X / CDNA4) attention-forward kernels.
+//
+// Written for gfx950 only: 64-lane wavefronts, v_mfma_f32_32x32x16_{f16,bf16},
+// ds_read_b64_tr_b16, buffer_load/store through wave-uniform resource descriptors.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+typedef float    f32x4  __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4  __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2  __attribute__((ext_vector_type(2)));
+typedef short    s16x4  __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4  __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
+typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16   bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16   bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ---- element-type traits: fp16 / bf16 inputs, fp32 accumulation ---------------------------
+struct F16 {
+    static constexpr int id = 0;
+    static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a),
+                                                     __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        f16x2 v = {(_Float16)lo, (_Float16)hi};   // v_cvt_pk_f16_f32 (round-to-nearest-even)
+        return __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ float lo(unsigned w) {
+        return (float)__builtin_bit_cast(f16x2, w)[0];
+    }
+    static __device__ __forceinline__ float hi(unsigned w) {
+        return (float)__builtin_bit_cast(f16x2, w)[1];
+    }
+    static __device__ __forceinline__ float one(uint16_t b) {
+        return (float)__builtin_bit_cast(_Float16, b);
+    }
+};
+
+struct BF16 {
+    static constexpr int id = 1;
+    static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a),
+                                                         __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        bf16x2 v = {(__bf16)lo, (__bf16)hi};      // v_cvt_pk_bf16_f32 (round-to-nearest-even)
+        return __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+    static __device__ __forceinline__ float one(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+};
+
+// ---- buffer resources (wave-uniform base + byte count; out-of-range loads read 0, stores drop) --
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+}
+__device__ __forceinline__ u32x2 buf_load8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, 0, 0);
+}
+
+// ---- LDS access ----------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char lds_char;
+
+__device__ __forceinline__ u32x4 lds_read16(const char* smem, unsigned off) {
+    return *reinterpret_cast<const u32x4*>(smem + off);
+}
+__device__ __forceinline__ void lds_write16(char* smem, unsigned off, u32x4 v) {
+    *reinterpret_cast<u32x4*>(smem + off) = v;
+}
+// ds_read_b64_tr_b16: per 16-lane group a [4 rows][16 cols] block of 16-bit elements comes back
+// column-major; lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i.
+__device__ __forceinline__ u32x2 lds_read_tr8(const char* smem, unsigned off) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s16x4*)(__attribute__((address_space(3))) void*)(smem + off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// value of the other 32-lane half's copy of x (lane l <-> lane l^32)
+__device__ __forceinline__ float swap_halves(float x) {
+    return __shfl_xor(x, 32, 64);
+}
+
+}  // namespace fa

@@ -1,0 +1,459 @@
+// fa_fwd_kernels.hip -- general-shape FlashAttention forward for gfx950 (MI355X / CDNA4).
+//
+// Replaces the reference's general-shape family
+//   flashattn_forward_wmma_kernel{,_v2,_v3,_v4}   FlashAttention/flashattn_forward_wmma/*.cu:49-346
+//   flashattn_forward_wmma_v5_cp_async            FlashAttention/flashattn_forward_memory_bound/*v5_cp_async.cu:99
+// (signature (Q,K,V,O,BH,N,D,scale); Q,K,V,O [BH,N,D] row-major; self-attention; grid over
+// (query block, BH)) with a design made for 64-lane wavefronts and MFMA, not a WMMA translation:
+//
+//   * one workgroup = 8 waves = 256 query rows of one (batch,head); each wave owns 32 rows.
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16 (K tile is the A operand from LDS, Q^T the B operand
+//     held in registers for the whole kernel).  The accumulator then has the QUERY on the lane
+//     and the KEYS in the 16 registers: the online-softmax row statistics are in-lane, no
+//     shuffles per tile, and the same registers (packed to 16 bit) are directly the B operand of
+//     O^T += V^T.P^T -- P never goes through LDS or cross-lane moves.
+//   * V^T fragments come from a row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
+//     the k-order permutation the accumulator imposes is absorbed by which 4-key groups each
+//     half-wave reads.
+//   * running max: the (negated) reference max of each row sits in a 16-register block that is
+//     the C-input of the first QK^T MFMA, so S arrives already shifted and p = exp2(S) needs no
+//     subtraction.  The reference max is only raised when a tile exceeds it by more than 2^kThr
+//     (wave-uniform rare branch) -- the two-term (alpha,beta) renormalisation of
+//     flashattn_streaming_16x16_mw.cu:200-229 / the FA-2 form of v12f.cu:193-220, applied lazily.
+//   * scale*log2(e) is folded into Q once per block; exp is v_exp_f32 (2^x).
+//   * K/V tiles (64 keys) are staged HBM/L2 -> registers -> LDS with the load issued a tile ahead
+//     (replaces the reference's cp.async ping-pong, v5_cp_async.cu:221-256), double-buffered,
+//     one barrier per tile; K image XOR-swizzled for ds_read_b128, V image laid out in 256-B
+//     [4 keys][32 cols] blocks so each half-wave's transposed read covers all 64 banks once.
+//   * buffer_load/buffer_store with a per-head resource descriptor give N-tail handling for free
+//     (rows >= N read 0 / are not stored); keys >= N are masked to -inf in the last tile only.
+#include "fa_common.hpp"
+
+namespace fa {
+
+constexpr int kWaves  = 8;
+constexpr int kBlockM = 32 * kWaves;   // query rows per workgroup
+constexpr int kBlockN = 64;            // keys per tile
+constexpr float kThr  = 8.0f;          // lazy-rescale threshold, log2 domain (P <= 2^8 fits fp16)
+
+template <int D> struct TileGeom {
+    static constexpr int kRowBytes  = D * 2;
+    static constexpr int kChunks    = D / 8;                 // 16-B chunks per row
+    static constexpr int kTileBytes = kBlockN * kRowBytes;   // one K (or V) tile
+    static constexpr int kBufBytes  = 2 * kTileBytes;        // K + V
+    static constexpr int kLdsBytes  = 2 * kBufBytes;         // double buffered
+    static constexpr int kLoads     = (kBlockN * kChunks) / (64 * kWaves);  // 16-B loads / thread / tile
+    static constexpr int kKSteps    = D / 16;                // MFMA k-steps over d
+    static constexpr int kDBlocks   = D / 32;                // 32-row blocks of O^T
+    // K image: row-major rows of D*2 bytes, 16-B chunk index XORed with a row-derived value so
+    // that the 16 lanes of a ds_read_b128 group (16 different rows, same chunk) hit 16 slots.
+    static __device__ __forceinline__ unsigned k_swz(unsigned row) {
+        return D == 64 ? ((row >> 1) & 7u) : (row & 15u);
+    }
+    static __device__ __forceinline__ unsigned k_off(unsigned row, unsigned chunk) {
+        return row * kRowBytes + ((chunk ^ k_swz(row)) << 4);
+    }
+    // V image: [key/4][d/32] blocks of 256 B, inside a block [key%4][32 cols] (64-B rows).  The
+    // 64-B row slot is rotated by the column block so a row's 16-B chunk writes spread over banks.
+    static __device__ __forceinline__ unsigned v_off(unsigned key, unsigned chunk) {
+        const unsigned dblk = chunk >> 2;
+        return ((key >> 2) * kDBlocks + dblk) * 256u + (((key & 3u) ^ (dblk & 1u)) << 6) + ((chunk & 3u) << 4);
+    }
+};
+
+template <typename T, int D, bool kOutF32>
+__global__ __launch_bounds__(64 * kWaves, 2)
+void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                   const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                   int N, int nqb, float scale_log2e)
+{
+    using G = TileGeom<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- block -> (head, query block): blocks that share K/V sit on one XCD, consecutively ----
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const unsigned bh = wgid / (unsigned)nqb;
+    const unsigned qb = wgid - bh * (unsigned)nqb;
+
+    const unsigned tid  = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane = tid & 63u;
+    const unsigned r = lane & 31u, h = lane >> 5;
+
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+
+    const unsigned q_row = qb * kBlockM + wave * 32u + r;
+
+    // ---- Q^T fragments (B operand of S^T = K.Q^T), pre-multiplied by scale*log2(e) ------------
+    u32x4 qf[G::kKSteps];
+#pragma unroll
+    for (int s = 0; s < G::kKSteps; ++s) {
+        u32x4 raw = buf_load16(rq, q_row * G::kRowBytes + (16u * s + 8u * h) * 2u);
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            raw[w] = T::pack2(T::lo(raw[w]) * scale_log2e, T::hi(raw[w]) * scale_log2e);
+        qf[s] = raw;
+    }
+
+    // ---- staging: each thread moves kLoads 16-B chunks of K and of V per tile -----------------
+    unsigned g_off[G::kLoads], k_lds[G::kLoads], v_lds[G::kLoads];
+#pragma unroll
+    for (int p = 0; p < G::kLoads; ++p) {
+        const unsigned idx = tid + p * 64u * kWaves;
+        const unsigned row = idx / G::kChunks, c = idx % G::kChunks;
+        g_off[p] = row * G::kRowBytes + c * 16u;
+        k_lds[p] = G::k_off(row, c);
+        v_lds[p] = G::kTileBytes + G::v_off(row, c);
+    }
+    u32x4 kst[G::kLoads], vst[G::kLoads];
+    auto stage_load = [&](unsigned kv0) {
+#pragma unroll
+        for (int p = 0; p < G::kLoads; ++p) {
+            kst[p] = buf_load16(rk, kv0 * G::kRowBytes + g_off[p]);
+            vst[p] = buf_load16(rv, kv0 * G::kRowBytes + g_off[p]);
+        }
+    };
+    auto stage_write = [&](unsigned buf) {
+#pragma unroll
+        for (int p = 0; p < G::kLoads; ++p) {
+            lds_write16(smem, buf * G::kBufBytes + k_lds[p], kst[p]);
+            lds_write16(smem, buf * G::kBufBytes + v_lds[p], vst[p]);
+        }
+    };
+
+    // ---- per-lane LDS read addresses -----------------------------------------------------------
+    // K (A operand of QK^T): lane (r,h) reads row kb*32+r, chunk 2s+h.  The swizzle term depends
+    // only on r for both key blocks.
+    const unsigned k_rd_row = r * G::kRowBytes;
+    const unsigned k_rd_swz = G::k_swz(r);
+    // V^T (A operand of PV): 16-lane group g covers 16 d-columns; lane 4q+p of the group supplies
+    // row q (key), columns 4p..4p+3.  Half-wave h takes the key groups 4h..4h+3 of every 8.
+    const unsigned i16 = lane & 15u, vq = i16 >> 2, vp = i16 & 3u, vg = (lane >> 4) & 1u;
+    unsigned v_rd[2];   // per parity of the column block (row-slot rotation)
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        v_rd[par] = G::kTileBytes + h * G::kDBlocks * 256u + ((vq ^ par) << 6) + vg * 32u + vp * 8u;
+
+    // ---- running state -------------------------------------------------------------------------
+    f32x16 o[G::kDBlocks];
+#pragma unroll
+    for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.0f;
+    f32x16 negm;   // -(reference max) of this lane's query row, replicated: C-input of QK^T
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.0f;
+    float l_part = 0.0f;   // this half-wave's share of the row sum
+
+    const int ntiles = (N + kBlockN - 1) / kBlockN;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned cur = t & 1u;
+        const char* kbuf = smem + cur * G::kBufBytes;
+        if (t + 1 < ntiles) stage_load((t + 1) * kBlockN);
+
+        // ---- S^T - m = K.Q^T + (-m) -------------------------------------------------------
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < G::kKSteps; ++ks) {
+                const u32x4 kf = lds_read16(kbuf, kb * 32u * G::kRowBytes + k_rd_row +
+                                                      (((2u * ks + h) ^ k_rd_swz) << 4));
+                s[kb] = T::mfma32(kf, qf[ks], ks == 0 ? negm : s[kb]);
+            }
+        }
+
+        // ---- keys >= N (last tile only): -inf so that p = 0 --------------------------------
+        if ((t + 1) * kBlockN > N) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                    if (key >= N) s[kb][i] = -INFINITY;
+                }
+        }
+
+        // ---- tile max relative to the reference max; raise the reference only when needed ------
+        float tmax = max3(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) tmax = max3(tmax, s[0][i], s[0][i + 1]);
+        tmax = max3(tmax, s[0][15], s[1][0]);
+#pragma unroll
+        for (int i = 1; i < 15; i += 2) tmax = max3(tmax, s[1][i], s[1][i + 1]);
+        tmax = fmaxf(tmax, s[1][15]);
+
+        if (t == 0 || __any(tmax > kThr)) {
+            const float mx = fmaxf(tmax, swap_halves(tmax));      // row max, same in both halves
+            const float delta = (t == 0) ? mx : fmaxf(mx, 0.0f);   // new reference = old + delta
+            const float alpha = (t == 0) ? 0.0f : fast_exp2(-delta);
+#pragma unroll
+            for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            l_part *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                negm[i] -= delta;
+                s[0][i] -= delta;
+                s[1][i] -= delta;
+            }
+        }
+
+        // ---- p = 2^(S - m), row-sum share, pack to 16 bit (B operand of PV) ----------------
+        u32x4 pk[4];
+        float lsum0 = 0.0f, lsum1 = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = fast_exp2(s[kb][i]);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                lsum0 += s[kb][i];
+                lsum1 += s[kb][i + 1];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    pk[kb * 2 + s2][w] = T::pack2(s[kb][8 * s2 + 2 * w], s[kb][8 * s2 + 2 * w + 1]);
+        }
+        l_part += lsum0 + lsum1;
+
+        // ---- O^T += V^T.P^T -------------------------------------------------------------------
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 vf;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const u32x2 half = lds_read_tr8(
+                        kbuf, v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
+                    vf[2 * jj] = half[0];
+                    vf[2 * jj + 1] = half[1];
+                }
+                o[db] = T::mfma32(vf, pk[ks], o[db]);
+            }
+        }
+
+        if (t + 1 < ntiles) stage_write(cur ^ 1u);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O[q_row][db*32 + 8g + 4h + 0..3] in o[db][4g..4g+3] ---
+    const float l = l_part + swap_halves(l_part);
+    const float inv = 1.0f / l;
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+#pragma unroll
+    for (int db = 0; db < G::kDBlocks; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned col = db * 32u + 8u * g + 4u * h;
+            const float a = o[db][4 * g] * inv, b = o[db][4 * g + 1] * inv;
+            const float c = o[db][4 * g + 2] * inv, d = o[db][4 * g + 3] * inv;
+            if constexpr (kOutF32) {
+                const f32x4 v = {a, b, c, d};
+                buf_store16(ro, (q_row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+            } else {
+                const u32x2 v = {T::pack2(a, b), T::pack2(c, d)};
+                buf_store8(ro, (q_row * D + col) * 2u, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic fallback: any D % 16 == 0 (D <= 256), the "single 16x16 MFMA fragment" kernel.
+// One wave = 16 query rows, 16 keys per step straight from global memory, v_mfma_f32_16x16x16.
+// S^T = K.Q^T again puts the query on the lane (col = lane&15) and 4 keys in the registers of
+// each of the four 16-lane groups; the row statistics are combined across the groups with two
+// xor-shuffles.  This is the replacement for the reference's 1-warp kernels
+// (flashattn_forward_wmma.cu:49-346, flashattn_fused_softmax_tensorcore_16x16.cu:41-136) and the
+// correctness path for head dims the tiled kernel is not instantiated for.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGenMaxD = 256;
+
+template <typename T, bool kOutF32>
+__global__ __launch_bounds__(64)
+void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                           const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                           int N, int D, int nqb, float scale_log2e)
+{
+    const unsigned bh = blockIdx.x / (unsigned)nqb, qb = blockIdx.x % (unsigned)nqb;
+    const unsigned lane = threadIdx.x & 63u, c16 = lane & 15u, g4 = lane >> 4;
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+    const unsigned q_row = qb * 16u + c16;
+    const int nks = D / 16;      // k-steps over d for QK^T
+    const int ndb = D / 16;      // 16-row blocks of O^T
+
+    // B operand of S^T = K.Q^T: lane (c16,g4) holds Q[q_row][16s + 4g4 + 0..3], scaled.
+    u32x2 qf[kGenMaxD / 16];
+#pragma unroll
+    for (int s = 0; s < kGenMaxD / 16; ++s) {
+        if (s < nks) {
+            u32x2 raw = buf_load8(rq, (q_row * D + 16u * s + 4u * g4) * 2u);
+            raw[0] = T::pack2(T::lo(raw[0]) * scale_log2e, T::hi(raw[0]) * scale_log2e);
+            raw[1] = T::pack2(T::lo(raw[1]) * scale_log2e, T::hi(raw[1]) * scale_log2e);
+            qf[s] = raw;
+        }
+    }
+    f32x4 o[kGenMaxD / 16];
+#pragma unroll
+    for (int db = 0; db < kGenMaxD / 16; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l_part = 0.0f;
+
+    for (int kv0 = 0; kv0 < N; kv0 += 16) {
+        // A operand: lane (c16,g4) holds K[kv0 + c16][16s + 4g4 + 0..3]
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kGenMaxD / 16; ++s) {
+            if (s < nks) {
+                const u32x2 kf = buf_load8(rk, ((kv0 + c16) * D + 16u * s + 4u * g4) * 2u);
+                s4 = T::mfma16(kf, qf[s], s4);
+            }
+        }
+        // s4[i] = S[q_row][kv0 + 4*g4 + i] (log2 domain)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (kv0 + 4 * (int)g4 + i >= N) s4[i] = -INFINITY;
+        float tmax = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = fast_exp2(m - m_new);   // m = -inf on the first tile -> 0
+        m = m_new;
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = fast_exp2(s4[i] - m_new);
+        l_part = l_part * alpha + (p[0] + p[1]) + (p[2] + p[3]);
+        // B operand of O^T += V^T.P^T: lane (c16,g4) holds P^T[k = 4g4 + i][q = c16] = p[i]
+        const u32x2 pf = {T::pack2(p[0], p[1]), T::pack2(p[2], p[3])};
+#pragma unroll
+        for (int db = 0; db < kGenMaxD / 16; ++db) {
+            if (db < ndb) {
+                // A operand: V^T[d = 16db + c16][k = 4g4 + i] = V[kv0 + 4g4 + i][16db + c16]
+                uint16_t e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned off = ((kv0 + 4u * g4 + i) * D + 16u * db + c16) * 2u;
+                    e[i] = __builtin_amdgcn_raw_buffer_load_b16(rv, off, 0, 0);
+                }
+                const u32x2 vf = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[db][i] *= alpha;
+                o[db] = T::mfma16(vf, pf, o[db]);
+            }
+        }
+    }
+    float l = l_part + __shfl_xor(l_part, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+    // o[db][i] = O[q_row][16db + 4g4 + i]
+#pragma unroll
+    for (int db = 0; db < kGenMaxD / 16; ++db) {
+        if (db < ndb) {
+            const unsigned col = 16u * db + 4u * g4;
+            if constexpr (kOutF32) {
+                const f32x4 v = {o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv};
+                buf_store16(ro, (q_row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+            } else {
+                const u32x2 v = {T::pack2(o[db][0] * inv, o[db][1] * inv), T::pack2(o[db][2] * inv, o[db][3] * inv)};
+                buf_store8(ro, (q_row * D + col) * 2u, v);
+            }
+        }
+    }
+}
+
+}  // namespace fa
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch (C++ linkage; the C-ABI lives in fa_capi.hip)
+// ---------------------------------------------------------------------------------------------
+namespace fa {
+
+template <typename T, int D, bool kOutF32>
+static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void* O,
+                               int BH, int N, float scale, hipStream_t stream)
+{
+    using G = TileGeom<D>;
+    auto kern = fa_fwd_kernel<T, D, kOutF32>;
+    static bool attr_set = false;   // dyn-LDS opt-in is per function, cached (SURVEY 8(b) "Ownership")
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nqb = (N + kBlockM - 1) / kBlockM;
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * kWaves), G::kLdsBytes, stream,
+                       static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                       static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e);
+    return hipGetLastError();
+}
+
+template <typename T, bool kOutF32>
+static hipError_t launch_generic(const void* Q, const void* K, const void* V, void* O,
+                                 int BH, int N, int D, float scale, hipStream_t stream)
+{
+    const int nqb = (N + 15) / 16;
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((fa_fwd_generic_kernel<T, kOutF32>), dim3((unsigned)nwg), dim3(64), 0, stream,
+                       static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                       static_cast<const uint16_t*>(V), O, N, D, nqb, scale * kLog2e);
+    return hipGetLastError();
+}
+
+template <typename T, bool kOutF32>
+static hipError_t dispatch_d(const void* Q, const void* K, const void* V, void* O,
+                             int BH, int N, int D, float scale, int algo, hipStream_t stream)
+{
+    if (algo != 1) {   // 0 = auto, 2 = force tiled
+        if (D == 64)  return launch_tiled<T, 64, kOutF32>(Q, K, V, O, BH, N, scale, stream);
+        if (D == 128) return launch_tiled<T, 128, kOutF32>(Q, K, V, O, BH, N, scale, stream);
+        if (algo == 2) return hipErrorInvalidValue;
+    }
+    return launch_generic<T, kOutF32>(Q, K, V, O, BH, N, D, scale, stream);
+}
+
+// algo: 0 auto, 1 generic single-fragment kernel, 2 tiled kernel (D in {64,128} only)
+hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                            int algo, hipStream_t stream)
+{
+    if (!Q || !K || !V || !O) return hipErrorInvalidValue;
+    if (BH <= 0 || N <= 0 || D <= 0 || D % 16 != 0 || D > kGenMaxD) return hipErrorInvalidValue;
+    if ((unsigned long long)N * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;  // per-head 32-bit offsets
+    if (in_dtype == 0)
+        return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
+                              : dispatch_d<F16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);
+    if (in_dtype == 1)
+        return out_dtype == 0 ? dispatch_d<BF16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
+                              : dispatch_d<BF16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fa

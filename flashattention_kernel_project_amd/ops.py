@@ -1,0 +1,117 @@
+"""torch-tensor front end over the C ABI, keeping the reference's argument lists.
+
+PyTorch is plumbing only (device memory + streams); every op goes through libfa_mi355.so.
+"""
+from __future__ import annotations
+
+import math
+
+from . import capi
+
+
+def attention_flops(bh: int, n: int, d: int) -> float:
+    """4*BH*N^2*D (QK^T + PV, non-causal) -- the reference's own count,
+    FlashAttention/flashattn_forward_memory_bound/flashattn_forward_wmma_memprofile.cu:508."""
+    return 4.0 * bh * n * n * d
+
+
+def attention_min_bytes(bh: int, n: int, d: int, in_bytes: int = 2, out_bytes: int = 4) -> float:
+    """3*BH*N*D*sizeof(in) + BH*N*D*sizeof(out): memprofile.cu:518-520."""
+    return 3.0 * bh * n * d * in_bytes + 1.0 * bh * n * d * out_bytes
+
+
+def _stream_ptr(stream):
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return getattr(stream, "cuda_stream", stream)
+
+
+def _dev_ptr(t, name: str, dtypes):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if t.dtype not in dtypes:
+        raise ValueError(f"{name} has dtype {t.dtype}, expected one of {dtypes}")
+    return t.data_ptr()
+
+
+def flashattn_forward_wmma(Q, K, V, O, BH: int, N: int, D: int, scale: float, stream=None) -> None:
+    """(Q,K,V,O,BH,N,D,scale) of flashattn_forward_wmma_kernel
+    (FlashAttention/flashattn_forward_wmma/flashattn_forward_wmma.cu:49-58).
+    Q,K,V: fp16 [BH,N,D]; O: fp32 [BH,N,D], fully overwritten."""
+    import torch
+    for name, t in (("Q", Q), ("K", K), ("V", V)):
+        if t.numel() != BH * N * D:
+            raise ValueError(f"{name} has {t.numel()} elements, expected BH*N*D = {BH * N * D}")
+    if O.numel() != BH * N * D:
+        raise ValueError("O has the wrong number of elements")
+    code = capi.lib().flashattn_forward_wmma(
+        _dev_ptr(Q, "Q", (torch.float16,)), _dev_ptr(K, "K", (torch.float16,)),
+        _dev_ptr(V, "V", (torch.float16,)), _dev_ptr(O, "O", (torch.float32,)),
+        BH, N, D, float(scale), _stream_ptr(stream))
+    capi.check("flashattn_forward_wmma", code)
+
+
+def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = capi.ALGO_AUTO,
+               out=None, stream=None):
+    """Attention forward on [B,H,N,d] (or [BH,N,d]) fp16/bf16 device tensors.
+    out_dtype: torch.float32 (the reference's output type, default) or the input dtype."""
+    import torch
+    if q.dim() == 3:
+        B, (H, N, d) = 1, q.shape
+    elif q.dim() == 4:
+        B, H, N, d = q.shape
+    else:
+        raise ValueError("q must be [B,H,N,d] or [BH,N,d]")
+    if k.shape != q.shape or v.shape != q.shape:
+        raise ValueError("q, k, v must have identical shapes (self-attention, Nq == Nk)")
+    if q.dtype not in (torch.float16, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("q, k, v must all be fp16 or all bf16")
+    in_dt = capi.F16 if q.dtype == torch.float16 else capi.BF16
+    if out_dtype is None:
+        out_dtype = torch.float32 if out is None else out.dtype
+    if out_dtype == torch.float32:
+        out_dt = capi.OUT_F32
+    elif out_dtype == q.dtype:
+        out_dt = capi.OUT_SAME
+    else:
+        raise ValueError("out_dtype must be torch.float32 or the input dtype")
+    if out is None:
+        out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
+    elif out.shape != q.shape or out.dtype != out_dtype:
+        raise ValueError("out has the wrong shape or dtype")
+    if scale is None:
+        scale = 1.0 / math.sqrt(d)
+    dts = (torch.float16, torch.bfloat16)
+    code = capi.lib().fa_forward_ex(
+        _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts),
+        _dev_ptr(out, "out", (out_dtype,)), B, H, N, d, float(scale), in_dt, out_dt, algo,
+        _stream_ptr(stream))
+    capi.check("fa_forward_ex", code)
+    return out
+
+
+def _streaming(fn_name: str, Q, K, V, O, num_batches: int, seq_len: int, scale: float, stream):
+    import torch
+    if Q.numel() != num_batches * 256 or K.numel() != num_batches * 16 * seq_len \
+            or V.numel() != num_batches * 16 * seq_len or O.numel() != num_batches * 256:
+        raise ValueError("tensor sizes do not match num_batches/seq_len")
+    code = getattr(capi.lib(), fn_name)(
+        _dev_ptr(Q, "Q", (torch.float16,)), _dev_ptr(K, "K", (torch.float16,)),
+        _dev_ptr(V, "V", (torch.float16,)), _dev_ptr(O, "O", (torch.float32,)),
+        num_batches, seq_len, float(scale), _stream_ptr(stream))
+    capi.check(fn_name, code)
+
+
+def flashattn_streaming_16x16_mw(Q, K, V, O, num_batches: int, seq_len: int, scale: float, stream=None) -> None:
+    """(Q,K,V,O,num_batches,seq_len,scale) of flashattn_streaming_16x16_kernel_mw
+    (Streaming_FlashAttention_Forward_Kernel/flashattn_streaming_16x16_mw.cu:73-81).
+    Q [B,16,16], K [B,16,L], V [B,L,16] fp16; O [B,16,16] fp32."""
+    _streaming("flashattn_streaming_16x16_mw", Q, K, V, O, num_batches, seq_len, scale, stream)
+
+
+def flashattn_streaming_16x16_mw_kt(Q, K_T, V, O, num_batches: int, seq_len: int, scale: float, stream=None) -> None:
+    """v8+ ABI: K_T [B,L,16] (flashattn_warp_spc/flashattn_streaming_16x16_mw_v8.cu:103-111)."""
+    _streaming("flashattn_streaming_16x16_mw_kt", Q, K_T, V, O, num_batches, seq_len, scale, stream)

@@ -1,0 +1,78 @@
+/*
+ * fa_mi355.h -- C ABI of libfa_mi355.so: FlashAttention forward for AMD Instinct MI355X (gfx950).
+ *
+ * The reference (jeehun98/FlashAttention_Kernel_Project) has no library and nothing `extern "C"`:
+ * every kernel is a C++ `__global__` launched with <<<grid,block[,smem]>>> from its own main().
+ * What the reference fixes is each kernel's ARGUMENT LIST, tensor layouts, dtypes and grid
+ * convention.  Each entry point below keeps one of those argument lists in the same order and
+ * adds a trailing stream handle (the reference always uses the null stream: pass NULL).
+ *
+ * All pointers are DEVICE pointers owned by the caller; nothing is allocated or freed here; O is
+ * fully overwritten (no need to pre-zero).  Launches are asynchronous with respect to the host.
+ * Return value: a hipError_t as int (0 = hipSuccess).  Unsupported shapes return
+ * hipErrorInvalidValue (1) -- the reference kernels silently `return` instead
+ * (flashattn_forward_wmma.cu:59-63); the library never calls exit().
+ *
+ * `stream` is a hipStream_t passed as void*.
+ */
+#ifndef FA_MI355_H
+#define FA_MI355_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_DTYPE_F16  0
+#define FA_DTYPE_BF16 1
+#define FA_OUT_F32    0   /* the reference's output type */
+#define FA_OUT_SAME   1   /* output in the input's 16-bit type */
+
+#define FA_ALGO_AUTO    0
+#define FA_ALGO_GENERIC 1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
+#define FA_ALGO_TILED   2 /* LDS-staged 256-row workgroups, D in {64,128} */
+
+/* General-shape forward.  Replaces
+ *   flashattn_forward_wmma_kernel(const half* Q, const half* K, const half* V, float* O,
+ *                                 int BH, int N, int D, float scale)
+ *   FlashAttention/flashattn_forward_wmma/flashattn_forward_wmma.cu:49-58 (and _v2.cu:53, _v3.cu:52,
+ *   _v4.cu:52, flashattn_forward_memory_bound/flashattn_forward_wmma_v5_cp_async.cu:99,
+ *   flashattn_forward_wmma_memprofile.cu:60), launched as <<<(ceil(N/BLOCK_M), BH), block, smem>>>
+ *   (flashattn_forward_wmma.cu:389-413).
+ * Q,K,V [BH,N,D] row-major fp16, O [BH,N,D] fp32, self-attention, no mask.
+ * D % 16 == 0 (as the reference requires, :63), D <= 256; any N >= 1 (tail rows/keys handled). */
+int flashattn_forward_wmma(const void* Q, const void* K, const void* V, float* O,
+                           int BH, int N, int D, float scale, void* stream);
+
+/* The same operation with the dtype / output / kernel choices BASELINE's configs need
+ * (bf16 inputs, 16-bit outputs, B and H separate).  BH = B*H.  Same layouts as above. */
+int fa_forward(const void* Q, const void* K, const void* V, void* O,
+               int B, int H, int N, int d, float scale,
+               int in_dtype, int out_dtype, void* stream);
+int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
+                  int B, int H, int N, int d, float scale,
+                  int in_dtype, int out_dtype, int algo, void* stream);
+
+/* 16x16 streaming family.  Replaces
+ *   flashattn_streaming_16x16_kernel_mw(const __half* Q, const __half* K, const __half* V, float* O,
+ *                                       int num_batches, int seq_len, float scale)
+ *   Streaming_FlashAttention_Forward_Kernel/flashattn_streaming_16x16_mw.cu:73-81 (same list in
+ *   _mw_fixed.cu:78, _mw_v2.cu:75, _mw_cpasync.cu:73, flashattn_warp_spc/..._v3..v7), launched as
+ *   <<<num_batches, 64>>> (mw.cu:368-377).
+ * Q [B,16,16], K [B,16,L] (k-major), V [B,L,16] fp16; O [B,16,16] fp32; O = y/(l+1e-6). */
+int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,
+                                 int num_batches, int seq_len, float scale, void* stream);
+
+/* v8+ ABI of the same family: second pointer is K_T [B,L,16], produced by the host pre-transpose
+ *   flashattn_streaming_16x16_kernel_mw_v8(const __half* Q, const __half* K_T, const __half* V, float* O,
+ *                                          int num_batches, int seq_len, float scale)
+ *   flashattn_warp_spc/flashattn_streaming_16x16_mw_v8.cu:103-111 (v10.cu:104, v11.cu:101). */
+int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, const void* V, float* O,
+                                    int num_batches, int seq_len, float scale, void* stream);
+
+/* Library identification: "fa_mi355 <version> gfx950". */
+const char* fa_mi355_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

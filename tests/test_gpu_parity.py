@@ -1,0 +1,261 @@
+"""GPU tier: the HIP path, called through the C ABI (libfa_mi355.so), against the CPU oracle on
+identical seeded inputs and against the committed golden vectors.
+
+Tolerance (BASELINE.json north_star): max-abs <= 1e-2 vs the naive fp32 CPU reference on the
+same fp16/bf16-rounded Q/K/V.  Tighter per-dtype bounds on the relative L2 error the reference
+prints (flashattn_streaming_16x16_mw.cu:383-391) are asserted as well.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MAX_ABS = 1e-2                       # north-star tolerance
+REL_L2 = {0: 2e-3, 1: 1.2e-2}        # fp16 / bf16 inputs (P is rounded to the input type)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _tdtype(torch, fmt):
+    return torch.float16 if fmt == 0 else torch.bfloat16
+
+
+def _to_dev(torch, bits, fmt):
+    return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).cuda().view(_tdtype(torch, fmt))
+
+
+def _run(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False, scale=None):
+    q, k, v = (_to_dev(torch, x, fmt) for x in (qb, kb, vb))
+    od = _tdtype(torch, fmt) if out_same else torch.float32
+    o = fa.fa_forward(q, k, v, scale=scale, out_dtype=od, algo=algo)
+    torch.cuda.synchronize()
+    return o.float().cpu().numpy()
+
+
+def _algos_for(d):
+    return (0, 1, 2) if d in (64, 128) else (0, 1)
+
+
+def _check(oracle, got, want, fmt, what, out_same=False):
+    ma = oracle.max_abs(got, want)
+    rl = oracle.rel_l2(got, want)
+    assert np.isfinite(got).all(), what
+    tol_rl = REL_L2[fmt] * (1.5 if out_same else 1.0)
+    assert ma <= MAX_ABS and rl <= tol_rl, f"{what}: max_abs={ma:.3e} rel_l2={rl:.3e}"
+
+
+def test_golden_general(fa, oracle, torch_cuda, golden_dir):
+    paths = sorted(p for p in glob.glob(os.path.join(golden_dir, "*.npz"))
+                   if not os.path.basename(p).startswith("s16_"))
+    assert paths
+    for path in paths:
+        z = np.load(path)
+        fmt = int(z["fmt"])
+        d = z["q"].shape[-1]
+        for algo in _algos_for(d):
+            for out_same in (False, True):
+                got = _run(fa, torch_cuda, z["q"], z["k"], z["v"], fmt, algo, out_same)
+                _check(oracle, got, z["expected"], fmt, f"{os.path.basename(path)} algo={algo} out_same={out_same}", out_same)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("d", [16, 32, 64, 128, 256])
+def test_shape_sweep_vs_oracle(fa, oracle, torch_cuda, fmt, d):
+    ns = [1, 15, 16, 17, 63, 64, 65, 127, 255, 256, 257, 513]
+    for i, n in enumerate(ns):
+        bh = 3 if n < 300 else 2
+        (q, k, v), (qb, kb, vb) = oracle.make_qkv(bh, n, d, fmt, seed=1000 + 13 * i + d)
+        want = oracle.forward(q, k, v, accum=0, nthreads=8)
+        for algo in _algos_for(d):
+            got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
+            _check(oracle, got, want, fmt, f"n={n} d={d} fmt={fmt} algo={algo}")
+
+
+def test_reference_wmma_entry_point(fa, oracle, torch_cuda):
+    """(Q,K,V,O,BH,N,D,scale) exactly as flashattn_forward_wmma_kernel takes them, with the
+    reference driver's deterministic fill (flashattn_forward_wmma.cu:368-373)."""
+    torch = torch_cuda
+    bh, n, d = 1, 128, 64
+    i = np.arange(bh * n * d, dtype=np.int64)
+    base = (i % 13).astype(np.float32) * np.float32(0.01)
+    qb = oracle.encode16(base, 0).reshape(bh, n, d)
+    kb = oracle.encode16(np.float32(0.5) * base, 0).reshape(bh, n, d)
+    vb = oracle.encode16(np.float32(0.3) * base, 0).reshape(bh, n, d)
+    Q, K, V = (_to_dev(torch, x, 0) for x in (qb, kb, vb))
+    O = torch.full((bh, n, d), float("nan"), dtype=torch.float32, device="cuda")  # must be fully overwritten
+    scale = 1.0 / np.sqrt(np.float32(d))
+    fa.flashattn_forward_wmma(Q, K, V, O, bh, n, d, scale)
+    torch.cuda.synchronize()
+    want = oracle.forward(*(oracle.decode16(x, 0) for x in (qb, kb, vb)), scale=scale)
+    _check(oracle, O.cpu().numpy(), want, 0, "wmma driver fill")
+
+
+def test_scale_argument_and_stream(fa, oracle, torch_cuda):
+    torch = torch_cuda
+    (q, k, v), (qb, kb, vb) = oracle.make_qkv(2, 200, 64, 0, seed=77)
+    want = oracle.forward(q, k, v, scale=0.3, nthreads=4)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got = _run(fa, torch, qb, kb, vb, 0, scale=0.3)
+    _check(oracle, got, want, 0, "scale=0.3 on a side stream")
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("d", [64, 128])
+def test_forced_rescale_branch(fa, oracle, torch_cuda, fmt, d):
+    """The lazy running-max update is a rare, data-dependent branch: force it.  Selected key rows
+    in later tiles are made (anti-)parallel to selected query rows so the row max jumps by far
+    more than the 2^8 threshold at chosen tiles -- upward several times, for some rows only, and
+    for some rows in one half of the tile only."""
+    n, bh = 448, 2
+    (q, k, v), _ = oracle.make_qkv(bh, n, d, fmt, seed=4242 + d)
+    rng = np.random.default_rng(5)
+    big = 6.0
+    for b in range(bh):
+        for qi in rng.choice(n, 40, replace=False):
+            for step, key in enumerate(sorted(rng.choice(np.arange(64, n), 3, replace=False))):
+                k[b, key] = q[b, qi] * (big * (step + 1) / np.linalg.norm(q[b, qi])) * np.sqrt(d) / 4
+        # a whole 32-row block of queries all spiking at the same late tile, and the first tile
+        # all-negative for them
+        k[b, 300] = 0
+        q[b, 100:132] *= 0.05
+        k[b, 300] = q[b, 100:132].mean(0) * 400
+    q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
+    qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
+    scores = np.einsum("bnd,bmd->bnm", q, k) / np.sqrt(d) * 1.4426950408889634
+    run_max = np.maximum.accumulate(scores.reshape(bh, n, n // 64, 64).max(-1), axis=-1)
+    jumps = (np.diff(run_max, axis=-1) > 8.0).sum()
+    assert jumps > 50, "input does not force the rescale branch"
+    want = oracle.forward(q, k, v, accum=1, nthreads=8)
+    for algo in (0, 1):
+        got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
+        _check(oracle, got, want, fmt, f"forced rescale d={d} fmt={fmt} algo={algo}")
+
+
+def test_extreme_logits_stay_finite(fa, oracle, torch_cuda):
+    """Large-magnitude scores (|s*scale| up to ~600): no overflow/NaN, still matches."""
+    (q, k, v), _ = oracle.make_qkv(1, 256, 64, 0, seed=99)
+    q *= 12.0
+    k *= 12.0
+    q, k = (oracle.decode16(oracle.encode16(x, 0), 0) for x in (q, k))
+    qb, kb, vb = (oracle.encode16(x, 0) for x in (q, k, v))
+    want = oracle.forward(q, k, v, accum=1, nthreads=8)
+    for algo in (0, 1):
+        got = _run(fa, torch_cuda, qb, kb, vb, 0, algo)
+        assert np.isfinite(got).all()
+        assert oracle.max_abs(got, want) <= 2e-2   # near-one-hot rows: |dO| ~ |V| * dP
+
+
+def test_bit_reproducible_and_head_independent(fa, oracle, torch_cuda):
+    _, (qb, kb, vb) = oracle.make_qkv(6, 300, 64, 1, seed=31)
+    a = _run(fa, torch_cuda, qb, kb, vb, 1)
+    b = _run(fa, torch_cuda, qb, kb, vb, 1)
+    assert np.array_equal(a, b)
+    sub = _run(fa, torch_cuda, qb[2:5], kb[2:5], vb[2:5], 1)
+    assert np.array_equal(sub, a[2:5])   # a (b,h) slice never depends on its neighbours
+
+
+def test_baseline_config_properties(fa, oracle, torch_cuda):
+    """BASELINE cfg 4 size (B=8,H=16,N=4096,d=64): sampled rows against the oracle plus
+    size-independent properties (convexity, constant-V, key-permutation invariance)."""
+    torch = torch_cuda
+    B, H, N, d = 8, 16, 4096, 64
+    for fmt in (0, 1):
+        dt = _tdtype(torch, fmt)
+        g = torch.Generator(device="cuda").manual_seed(1234 + fmt)
+        q = torch.randn(B, H, N, d, generator=g, device="cuda", dtype=torch.float32).to(dt)
+        k = torch.randn(B, H, N, d, generator=g, device="cuda", dtype=torch.float32).to(dt)
+        v = torch.randn(B, H, N, d, generator=g, device="cuda", dtype=torch.float32).to(dt)
+        o = fa.fa_forward(q, k, v)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        # sampled (b,h) slices, 64 rows each, full N keys, on the CPU oracle
+        for (b, h, r0) in [(0, 0, 0), (3, 7, 1000), (7, 15, 4032), (5, 2, 2040)]:
+            qs, ks, vs = (t[b, h].float().cpu().numpy()[None] for t in (q, k, v))
+            want = oracle.forward(qs, ks, vs, accum=0, nthreads=8, row_range=(r0, r0 + 64))
+            got = o[b, h, r0:r0 + 64].cpu().numpy()
+            _check(oracle, got, want[0, r0:r0 + 64], fmt, f"cfg4 slice b={b} h={h} r0={r0} fmt={fmt}")
+        # convexity: every output lies inside the per-column range of V
+        vmin = v.float().amin(dim=2, keepdim=True)
+        vmax = v.float().amax(dim=2, keepdim=True)
+        assert bool(((o >= vmin - 1e-3) & (o <= vmax + 1e-3)).all())
+        # key permutation invariance (same permutation applied to K and V)
+        perm = torch.randperm(N, generator=g, device="cuda")
+        o2 = fa.fa_forward(q[:2], k[:2, :, perm].contiguous(), v[:2, :, perm].contiguous())
+        assert float((o2 - o[:2]).abs().max()) <= 5e-3
+        # constant V -> constant output
+        vc = torch.ones_like(v[:1]) * 0.5
+        oc = fa.fa_forward(q[:1], k[:1], vc)
+        assert float((oc - 0.5).abs().max()) <= 2e-3
+        del q, k, v, o, o2, oc
+        torch.cuda.empty_cache()
+
+
+def test_d128_long_sequence_slice(fa, oracle, torch_cuda):
+    """BASELINE cfg 5 per-head shape (N=8192, d=128), a few heads, sampled rows."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q, k, v = (torch.randn(1, 4, 8192, 128, generator=g, device="cuda").half() for _ in range(3))
+    o = fa.fa_forward(q, k, v)
+    torch.cuda.synchronize()
+    for (h, r0) in [(0, 0), (3, 8128), (2, 4000)]:
+        qs, ks, vs = (t[0, h].float().cpu().numpy()[None] for t in (q, k, v))
+        want = oracle.forward(qs, ks, vs, accum=0, nthreads=8, row_range=(r0, r0 + 32))
+        _check(oracle, o[0, h, r0:r0 + 32].cpu().numpy(), want[0, r0:r0 + 32], 0, f"cfg5 slice h={h} r0={r0}")
+
+
+# ---------------------------------------------------------------- 16x16 streaming family
+
+def _s16_run(fa, torch, qb, kb, vb, kt=False):
+    b, l = qb.shape[0], vb.shape[1]
+    Q, K, V = (_to_dev(torch, x, 0) for x in (qb, kb, vb))
+    O = torch.full((b, 16, 16), float("nan"), dtype=torch.float32, device="cuda")
+    if kt:
+        KT = K.transpose(1, 2).contiguous()   # host pre-transpose of the v8+ ABI
+        fa.flashattn_streaming_16x16_mw_kt(Q, KT, V, O, b, l, 0.25)
+    else:
+        fa.flashattn_streaming_16x16_mw(Q, K, V, O, b, l, 0.25)
+    torch.cuda.synchronize()
+    return O.cpu().numpy()
+
+
+def test_streaming16_golden(fa, oracle, torch_cuda, golden_dir):
+    for path in sorted(glob.glob(os.path.join(golden_dir, "s16_*.npz"))):
+        z = np.load(path)
+        for kt in (False, True):
+            got = _s16_run(fa, torch_cuda, z["q"], z["k"], z["v"], kt)
+            _check(oracle, got, z["expected"], 0, f"{os.path.basename(path)} kt={kt}")
+
+
+def test_streaming16_reference_driver_shape(fa, oracle, torch_cuda):
+    """NUM_BATCH=1024, SEQ_LEN=128, N(0,1) seed 42, scale = 1/sqrt(16)
+    (flashattn_streaming_16x16_mw.cu:322-349), plus ragged L and a batch count that does not
+    fill the last workgroup."""
+    for b, l in [(1024, 128), (1023, 128), (5, 16), (7, 200), (3, 24)]:
+        nq, nk = b * 256, b * 16 * l
+        qb = oracle.encode16(oracle.fill(nq, 42, 0), 0).reshape(b, 16, 16)
+        kb = oracle.encode16(oracle.fill(nk, 42, nq), 0).reshape(b, 16, l)
+        vb = oracle.encode16(oracle.fill(nk, 42, nq + nk), 0).reshape(b, l, 16)
+        want = oracle.streaming_16x16(*(oracle.decode16(x, 0) for x in (qb, kb, vb)), scale=0.25)
+        a = _s16_run(fa, torch_cuda, qb, kb, vb, False)
+        c = _s16_run(fa, torch_cuda, qb, kb, vb, True)
+        _check(oracle, a, want, 0, f"s16 b={b} l={l}")
+        assert np.array_equal(a, c), "K and K_T entry points must agree bit for bit"
+
+
+def test_device_rejects_bad_shapes(fa, torch_cuda):
+    torch = torch_cuda
+    q = torch.zeros(1, 128, 24, dtype=torch.float16, device="cuda")
+    with pytest.raises(fa.FaError):
+        fa.fa_forward(q, q, q)                       # D % 16 != 0
+    q = torch.zeros(1, 128, 32, dtype=torch.float16, device="cuda")
+    with pytest.raises(fa.FaError):
+        fa.fa_forward(q, q, q, algo=2)               # tiled kernel needs D in {64,128}
