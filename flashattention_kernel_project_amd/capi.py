@@ -43,6 +43,21 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7).  Device
+    pointers and stream handles are only meaningful inside ONE HIP runtime, so that copy must be
+    in the process before libfa_mi355.so is loaded: its DT_NEEDED libamdhip64.so.7 then binds to
+    it by soname instead of pulling /opt/rocm's copy in as a second runtime (which sees no device:
+    hipErrorNoDevice).  A pure C/C++ host (bench/fa_bench) links /opt/rocm's runtime directly."""
+    try:
+        import torch
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Load the HIP library.  No fallback: a missing library is an error."""
     global _lib
@@ -51,6 +66,7 @@ def lib() -> C.CDLL:
             raise FileNotFoundError(
                 f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C flashattention_kernel_project_amd/csrc`")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.flashattn_forward_wmma.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]

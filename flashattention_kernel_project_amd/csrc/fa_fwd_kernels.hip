@@ -15,12 +15,12 @@
 //   * V^T fragments come from a row-major V tile through ds_read_b64_tr_b16 (hardware transpose);
 //     the k-order permutation the accumulator imposes is absorbed by which 4-key groups each
 //     half-wave reads.
-//   * running max: the (negated) reference max of each row sits in a 16-register block that is
-//     the C-input of the first QK^T MFMA, so S arrives already shifted and p = exp2(S) needs no
-//     subtraction.  The reference max is only raised when a tile exceeds it by more than 2^kThr
-//     (wave-uniform rare branch) -- the two-term (alpha,beta) renormalisation of
-//     flashattn_streaming_16x16_mw.cu:200-229 / the FA-2 form of v12f.cu:193-220, applied lazily.
-//   * scale*log2(e) is folded into Q once per block; exp is v_exp_f32 (2^x).
+//   * running max: p = 2^(c*S - m_ref) is one v_fma + one v_exp per element (c = scale*log2(e),
+//     applied in fp32 to the exact fp32 QK^T sums, as the reference's `acc * scale` does -- folding
+//     c into the 16-bit Q would perturb large logits by |s|*2^-11).  The reference max m_ref of a
+//     row is only raised when a tile exceeds it by more than 2^kThr (wave-uniform rare branch):
+//     the two-term (alpha,beta) renormalisation of flashattn_streaming_16x16_mw.cu:200-229 / the
+//     FA-2 form of v12f.cu:193-220, applied lazily.
 //   * K/V tiles (64 keys) are staged HBM/L2 -> registers -> LDS with the load issued a tile ahead
 //     (replaces the reference's cp.async ping-pong, v5_cp_async.cu:221-256), double-buffered,
 //     one barrier per tile; K image XOR-swizzled for ds_read_b128, V image laid out in 256-B
@@ -90,14 +90,17 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
 
     const unsigned q_row = qb * kBlockM + wave * 32u + r;
 
-    // ---- Q^T fragments (B operand of S^T = K.Q^T), pre-multiplied by scale*log2(e) ------------
+    // ---- Q^T fragments (B operand of S^T = K.Q^T), resident for the whole kernel ---------------
+    // c = |scale|*log2(e) is applied to the fp32 scores; a negative scale flips Q's sign bits so
+    // that the row max of c*S is always c*max(S).
+    const float c = fabsf(scale_log2e);
+    const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
     u32x4 qf[G::kKSteps];
 #pragma unroll
     for (int s = 0; s < G::kKSteps; ++s) {
         u32x4 raw = buf_load16(rq, q_row * G::kRowBytes + (16u * s + 8u * h) * 2u);
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-            raw[w] = T::pack2(T::lo(raw[w]) * scale_log2e, T::hi(raw[w]) * scale_log2e);
+        for (int w = 0; w < 4; ++w) raw[w] ^= q_flip;
         qf[s] = raw;
     }
 
@@ -146,9 +149,10 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
     for (int db = 0; db < G::kDBlocks; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] = 0.0f;
-    f32x16 negm;   // -(reference max) of this lane's query row, replicated: C-input of QK^T
+    f32x16 zero16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) negm[i] = 0.0f;
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
+    float m_ref = 0.0f;    // reference max of this lane's query row, in log2 units (c*S)
     float l_part = 0.0f;   // this half-wave's share of the row sum
 
     const int ntiles = (N + kBlockN - 1) / kBlockN;
@@ -162,7 +166,7 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
         const char* kbuf = smem + cur * G::kBufBytes;
         if (t + 1 < ntiles) stage_load((t + 1) * kBlockN);
 
-        // ---- S^T - m = K.Q^T + (-m) -------------------------------------------------------
+        // ---- S^T = K.Q^T (raw fp32 scores) ------------------------------------------------
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -170,7 +174,7 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
             for (int ks = 0; ks < G::kKSteps; ++ks) {
                 const u32x4 kf = lds_read16(kbuf, kb * 32u * G::kRowBytes + k_rd_row +
                                                       (((2u * ks + h) ^ k_rd_swz) << 4));
-                s[kb] = T::mfma32(kf, qf[ks], ks == 0 ? negm : s[kb]);
+                s[kb] = T::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[kb]);
             }
         }
 
@@ -185,39 +189,35 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
                 }
         }
 
-        // ---- tile max relative to the reference max; raise the reference only when needed ------
+        // ---- tile max vs the reference max; raise the reference only when needed ----------------
         float tmax = max3(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
         for (int i = 3; i < 15; i += 2) tmax = max3(tmax, s[0][i], s[0][i + 1]);
         tmax = max3(tmax, s[0][15], s[1][0]);
 #pragma unroll
         for (int i = 1; i < 15; i += 2) tmax = max3(tmax, s[1][i], s[1][i + 1]);
-        tmax = fmaxf(tmax, s[1][15]);
+        tmax = fmaxf(tmax, s[1][15]) * c;   // log2 units
 
-        if (t == 0 || __any(tmax > kThr)) {
-            const float mx = fmaxf(tmax, swap_halves(tmax));      // row max, same in both halves
-            const float delta = (t == 0) ? mx : fmaxf(mx, 0.0f);   // new reference = old + delta
-            const float alpha = (t == 0) ? 0.0f : fast_exp2(-delta);
+        if (t == 0 || __any(tmax - m_ref > kThr)) {
+            const float mx = fmaxf(tmax, swap_halves(tmax));         // row max, same in both halves
+            const float m_new = (t == 0) ? mx : fmaxf(mx, m_ref);
+            const float alpha = (t == 0) ? 0.0f : fast_exp2(m_ref - m_new);
+            m_ref = m_new;
 #pragma unroll
             for (int db = 0; db < G::kDBlocks; ++db)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
             l_part *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                negm[i] -= delta;
-                s[0][i] -= delta;
-                s[1][i] -= delta;
-            }
         }
 
-        // ---- p = 2^(S - m), row-sum share, pack to 16 bit (B operand of PV) ----------------
+        // ---- p = 2^(c*S - m_ref), row-sum share, pack to 16 bit (B operand of PV) -----------
         u32x4 pk[4];
         float lsum0 = 0.0f, lsum1 = 0.0f;
+        const float neg_m = -m_ref;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = fast_exp2(s[kb][i]);
+            for (int i = 0; i < 16; ++i) s[kb][i] = fast_exp2(__builtin_fmaf(s[kb][i], c, neg_m));
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 lsum0 += s[kb][i];
@@ -304,17 +304,11 @@ void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
     const int nks = D / 16;      // k-steps over d for QK^T
     const int ndb = D / 16;      // 16-row blocks of O^T
 
-    // B operand of S^T = K.Q^T: lane (c16,g4) holds Q[q_row][16s + 4g4 + 0..3], scaled.
+    // B operand of S^T = K.Q^T: lane (c16,g4) holds Q[q_row][16s + 4g4 + 0..3].
     u32x2 qf[kGenMaxD / 16];
 #pragma unroll
-    for (int s = 0; s < kGenMaxD / 16; ++s) {
-        if (s < nks) {
-            u32x2 raw = buf_load8(rq, (q_row * D + 16u * s + 4u * g4) * 2u);
-            raw[0] = T::pack2(T::lo(raw[0]) * scale_log2e, T::hi(raw[0]) * scale_log2e);
-            raw[1] = T::pack2(T::lo(raw[1]) * scale_log2e, T::hi(raw[1]) * scale_log2e);
-            qf[s] = raw;
-        }
-    }
+    for (int s = 0; s < kGenMaxD / 16; ++s)
+        if (s < nks) qf[s] = buf_load8(rq, (q_row * D + 16u * s + 4u * g4) * 2u);
     f32x4 o[kGenMaxD / 16];
 #pragma unroll
     for (int db = 0; db < kGenMaxD / 16; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -330,10 +324,10 @@ void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
                 s4 = T::mfma16(kf, qf[s], s4);
             }
         }
-        // s4[i] = S[q_row][kv0 + 4*g4 + i] (log2 domain)
+        // s4[i] = S[q_row][kv0 + 4*g4 + i]; to the log2 domain in fp32
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (kv0 + 4 * (int)g4 + i >= N) s4[i] = -INFINITY;
+            s4[i] = (kv0 + 4 * (int)g4 + i >= N) ? -INFINITY : s4[i] * scale_log2e;
         float tmax = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));

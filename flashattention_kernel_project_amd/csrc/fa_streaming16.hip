@@ -37,10 +37,8 @@ void fa_streaming16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + (size_t)b * 16 * L, 32u * L);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + (size_t)b * 16 * L, 32u * L);
 
-    // B operand of S^T = K.Q^T: Q[q = c16][k = 4g4 + j], scaled by scale*log2(e)
-    u32x2 qf = buf_load8(rq, (c16 * 16u + 4u * g4) * 2u);
-    qf[0] = T::pack2(T::lo(qf[0]) * scale_log2e, T::hi(qf[0]) * scale_log2e);
-    qf[1] = T::pack2(T::lo(qf[1]) * scale_log2e, T::hi(qf[1]) * scale_log2e);
+    // B operand of S^T = K.Q^T: Q[q = c16][k = 4g4 + j]
+    const u32x2 qf = buf_load8(rq, (c16 * 16u + 4u * g4) * 2u);
 
     auto load_k = [&](unsigned kv0) -> u32x2 {   // A operand: K[key = kv0 + c16][k = 4g4 + j]
         if constexpr (kKT) {
@@ -68,10 +66,10 @@ void fa_streaming16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
     for (unsigned kv0 = 0; kv0 < L; kv0 += 16) {
         const u32x2 kc = kf, vc = vf;
         if (kv0 + 16 < L) { kf = load_k(kv0 + 16); vf = load_v(kv0 + 16); }
-        f32x4 s4 = T::mfma16(kc, qf, f32x4{0.f, 0.f, 0.f, 0.f});   // S[q=c16][kv0 + 4g4 + i], log2 domain
+        f32x4 s4 = T::mfma16(kc, qf, f32x4{0.f, 0.f, 0.f, 0.f});   // S[q=c16][kv0 + 4g4 + i]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (kv0 + 4u * g4 + i >= L) s4[i] = -INFINITY;          // ragged tail (reference assumes L%16==0)
+        for (int i = 0; i < 4; ++i)   // `acc * scale` in fp32 (mw.cu:283), to log2 units; ragged tail masked
+            s4[i] = (kv0 + 4u * g4 + i >= L) ? -INFINITY : s4[i] * scale_log2e;
         float tmax = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
