@@ -11,7 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 F16, BF16 = 0, 1
 OUT_F32, OUT_SAME = 0, 1
-ALGO_AUTO, ALGO_GENERIC, ALGO_TILED = 0, 1, 2
+ALGO_AUTO, ALGO_GENERIC, ALGO_TILED, ALGO_PIPE, ALGO_PINGPONG, ALGO_INTERLEAVED, ALGO_INTERLEAVED_2WG = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/fa_mi355.h declares
 SYMBOLS = (

@@ -9,9 +9,27 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
 hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
                                 int num_batches, int seq_len, float scale, bool k_transposed,
                                 hipStream_t stream);
+hipError_t pp_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, float scale, unsigned long long* diag, int mode, hipStream_t stream);
+hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream);
 }  // namespace fa
 
 extern "C" {
+
+// Diagnostic only (not in the public header): compute / stage-wait / barrier time of the interleaved kernel.
+int fa_debug_il_times(const void* Q, const void* K, const void* V, void* O,
+                      int BH, int N, float scale, unsigned long long* diag, int waves, void* stream)
+{
+    return (int)fa::il_diag_dispatch(Q, K, V, O, BH, N, scale, diag, waves, static_cast<hipStream_t>(stream));
+}
+
+// Diagnostic only (not declared in the public header): phase-time stamps of the ping-pong kernel.
+int fa_debug_pp_phase_times(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, float scale, unsigned long long* diag, int mode, void* stream)
+{
+    return (int)fa::pp_diag_dispatch(Q, K, V, O, BH, N, scale, diag, mode, static_cast<hipStream_t>(stream));
+}
 
 int flashattn_forward_wmma(const void* Q, const void* K, const void* V, float* O,
                            int BH, int N, int D, float scale, void* stream)
@@ -25,7 +43,7 @@ int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
                   int in_dtype, int out_dtype, int algo, void* stream)
 {
     if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
-    if (algo < FA_ALGO_AUTO || algo > FA_ALGO_TILED) return (int)hipErrorInvalidValue;
+    if (algo < FA_ALGO_AUTO || algo > FA_ALGO_INTERLEAVED_2WG) return (int)hipErrorInvalidValue;
     if (out_dtype != FA_OUT_F32 && out_dtype != FA_OUT_SAME) return (int)hipErrorInvalidValue;
     return (int)fa::forward_dispatch(Q, K, V, O, B * H, N, d, scale, in_dtype, out_dtype, algo,
                                      static_cast<hipStream_t>(stream));

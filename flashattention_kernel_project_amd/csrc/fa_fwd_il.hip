@@ -1,0 +1,518 @@
+// fa_fwd_il.hip -- interleaved (software-pipelined) tiled attention forward for gfx950.
+//
+// Same data layout, MFMA orientation and LDS images as fa_fwd_kernels.hip (see the header there);
+// what changes is the instruction stream of a wave.  Measured on MI355X (tools/microbench/
+// valu_rate.hip): the softmax VALU slice that belongs to one 32x32x16 MFMA at d=64 (2 fma, 2 exp,
+// 1 cvt_pk, 2 add, 1 max3) costs ~44 issue cycles for a lone wave and ~32 per wave when both
+// waves of a SIMD issue VALU together, and an MFMA placed between such slices adds only ~7 cycles.
+// So the stream that keeps both pipes busy is NOT "matrix phase, then vector phase" but one MFMA
+// followed by its slice of independent vector work, in every wave, all the time.
+//
+// That needs every MFMA of an iteration to be independent of that iteration's vector work:
+//
+//   iteration t:   MFMA:  S(t+1) = K(t+1).Q^T          and   O^T += V(t-1)^T.P(t-1)^T
+//                  VALU:  P(t) = 2^(c*S(t) - m), pack, row sums;   row max of S(t+1) at the end
+//
+// i.e. QK^T runs one tile ahead of the softmax and PV one tile behind it (two score sets and two
+// packed-P sets, named statically and swapped by unrolling the loop twice).  The iteration is
+// written as a sequence of slots { MFMA c ; LDS operand reads for MFMA c+4 ; VALU slice c } with a
+// scheduling fence between slots, so program order IS issue order.  The lazy running-max update
+// (rare, wave-uniform branch at the end of the iteration) rescales O, l and the packed P(t) that
+// has not been multiplied into O yet.
+//
+// K(t+2) and V(t) are fetched HBM/L2 -> registers at the top of iteration t and written to LDS at
+// its end (2-deep rings for K and V, one barrier per iteration): the role of the reference's
+// loader warp + cp.async ping-pong (flashattn_streaming_16x16_mw_v10.cu:156-195,
+// flashattn_forward_wmma_v5_cp_async.cu:221-256).
+#include "fa_tile.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace fa {
+
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+constexpr int kReadAhead = 4;             // LDS operand reads run this many MFMAs ahead
+constexpr int kFragRing  = kReadAhead + 1;
+
+// kDiag: diagnostic build only (never the shipped path): per-wave s_memtime sums of the time spent
+// computing, waiting for + writing the staged tiles, and at the barrier -> diag[wg][wave][4].
+//
+// W = waves per workgroup (32 query rows each).  W = 4 with two workgroups per CU is the shipped
+// shape: the two waves that share a SIMD then belong to DIFFERENT workgroups.  The SIMD arbitrates
+// between its waves by age, not fairly (measured: with W = 8 the older wave of each pair finishes a
+// tile in ~1360 cycles, the younger in ~2180, and the older then idles at the workgroup barrier);
+// across workgroups nobody waits for the slower wave, so the unfairness costs nothing.
+template <typename T, int D, bool kOutF32, int W, bool kDiag = false, int kAblate = 0>
+__global__ __launch_bounds__(64 * W, 2)
+void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                      const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                      int N, int nqb, float scale_log2e, unsigned long long* __restrict__ diag = nullptr)
+{
+    unsigned long long tm_c = 0, tm_w = 0, tm_b = 0, tm_last = 0;
+    auto stamp = [&](unsigned long long& acc) {
+        if constexpr (kDiag) {
+            unsigned long long now;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            acc += now - tm_last;
+            tm_last = now;
+        }
+    };
+    using G = TileGeom<D>;
+    constexpr int kLoadsW = (kBlockN * G::kChunks) / (64 * W);   // 16-B staging loads per thread per tile
+    constexpr int kRowsWG = 32 * W;                              // query rows per workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0][K1][V0][V1]
+
+    // ---- block -> (head, query block): blocks that share K/V sit on one XCD, consecutively ----
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const unsigned bh = wgid / (unsigned)nqb;
+    const unsigned qb = wgid - bh * (unsigned)nqb;
+
+    const unsigned tid  = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane = tid & 63u;
+    const unsigned r = lane & 31u, h = lane >> 5;
+
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+
+    const unsigned q_row = qb * kRowsWG + wave * 32u + r;
+
+    // ---- Q^T fragments (B operand of S^T = K.Q^T), resident for the whole kernel ---------------
+    const float c = fabsf(scale_log2e);
+    const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
+    u32x4 qf[G::kKSteps];
+#pragma unroll
+    for (int s = 0; s < G::kKSteps; ++s) {
+        u32x4 raw = buf_load16(rq, q_row * G::kRowBytes + (16u * s + 8u * h) * 2u);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) raw[w] ^= q_flip;
+        qf[s] = raw;
+    }
+
+    // ---- staging ----------------------------------------------------------------------------
+    unsigned g_off[kLoadsW], k_lds[kLoadsW], v_lds[kLoadsW];
+#pragma unroll
+    for (int p = 0; p < kLoadsW; ++p) {
+        const unsigned idx = tid + p * 64u * W;
+        const unsigned row = idx / G::kChunks, ch = idx % G::kChunks;
+        g_off[p] = row * G::kRowBytes + ch * 16u;
+        k_lds[p] = G::k_off(row, ch);
+        v_lds[p] = 2u * G::kTileBytes + G::v_off(row, ch);
+    }
+    u32x4 kst[kLoadsW], vst[kLoadsW];
+    // Tiles past the end read zeros through the buffer bounds and land in ring slots nobody
+    // reads any more: staging is unconditional and the loop body stays branch-free.
+    auto load_k = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < kLoadsW; ++p) kst[p] = buf_load16(rk, (unsigned)tile * kBlockN * G::kRowBytes + g_off[p]);
+    };
+    auto load_v = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < kLoadsW; ++p) vst[p] = buf_load16(rv, (unsigned)tile * kBlockN * G::kRowBytes + g_off[p]);
+    };
+    auto write_k = [&](unsigned buf) {
+#pragma unroll
+        for (int p = 0; p < kLoadsW; ++p) lds_write16(smem, buf * G::kTileBytes + k_lds[p], kst[p]);
+    };
+    auto write_v = [&](unsigned buf) {
+#pragma unroll
+        for (int p = 0; p < kLoadsW; ++p) lds_write16(smem, buf * G::kTileBytes + v_lds[p], vst[p]);
+    };
+
+    // ---- per-lane LDS read addresses (see fa_fwd_kernels.hip) -----------------------------------
+    const unsigned k_rd_row = r * G::kRowBytes;
+    const unsigned k_rd_swz = G::k_swz(r);
+    const unsigned i16 = lane & 15u, vq = i16 >> 2, vp = i16 & 3u, vg = (lane >> 4) & 1u;
+    unsigned v_rd[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        v_rd[par] = 2u * G::kTileBytes + h * G::kDBlocks * 256u + ((vq ^ par) << 6) + vg * 32u + vp * 8u;
+
+    // ---- running state -------------------------------------------------------------------------
+    f32x16 o[G::kDBlocks];
+#pragma unroll
+    for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.0f;
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
+    float m_ref = 0.0f;    // reference max of this lane's query row, log2 units (c*S)
+    float l_part = 0.0f;   // this half-wave's share of the row sum
+
+    const int ntiles = (N + kBlockN - 1) / kBlockN;
+    const bool partial = (N % kBlockN) != 0;
+
+    constexpr int nQK = 2 * G::kKSteps;   // MFMAs of S(t+1) = K.Q^T
+    constexpr int nPV = 4 * G::kDBlocks;  // MFMAs of O^T += V^T.P^T
+
+    auto keep_alive = [&](u32x4& v) { asm volatile("" : "+v"(v)); };
+    auto mask_tail = [&](int tile, f32x16 (&s)[2]) {   // keys >= N -> -inf (p = 0)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = tile * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                if (key >= N) s[kb][i] = -INFINITY;
+            }
+    };
+    auto rescale = [&](float tmax, u32x4 (&pk)[4]) {   // rare: raise the reference max
+        const float mx = fmaxf(tmax, swap_halves(tmax));
+        const float m_new = fmaxf(mx, m_ref);
+        const float alpha = fast_exp2(m_ref - m_new);
+        m_ref = m_new;
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        l_part *= alpha;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)   // P(t) is still waiting for its PV: bring it to the new scale too
+#pragma unroll
+            for (int w = 0; w < 4; ++w) pk[k4][w] = T::pack2(T::lo(pk[k4][w]) * alpha, T::hi(pk[k4][w]) * alpha);
+    };
+
+    // One iteration.  s_cur: raw S(t), overwritten by P(t); s_nxt: receives raw S(t+1);
+    // pk_prev: packed P(t-1) (consumed by PV); pk_cur: receives packed P(t).
+    auto iter = [&](auto has_prev_c, auto has_next_c, int t, bool mask_next,
+                    f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[4], u32x4 (&pk_cur)[4]) {
+        constexpr bool kHasPrev = decltype(has_prev_c)::value;
+        constexpr bool kHasNext = decltype(has_next_c)::value;
+        constexpr int nQ = kHasNext ? nQK : 0, nP = kHasPrev ? nPV : 0, nAll = nQ + nP;
+        constexpr int kSteps = 16;   // VALU pair-steps (2 scores each)
+        constexpr int kStageSlot = nAll > 0 ? (3 * nAll) / 4 : -1;   // slot in front of which the staged tiles are written
+
+        if constexpr (kAblate != 4) {
+            load_k(t + 2);
+            load_v(t);
+        }
+
+        const unsigned kbuf = (unsigned)(t + 1) & 1u, vbuf = (unsigned)(t + 1) & 1u;   // K(t+1), V(t-1)
+        u32x4 frag[kFragRing];
+        auto issue_reads = [&](auto ic) {   // LDS operand reads of MFMA ic
+            constexpr int i = decltype(ic)::value;
+            if constexpr (kAblate == 1) {   // timing ablation: no LDS operand reads
+                if constexpr (i < nAll) frag[i % kFragRing] = qf[i % G::kKSteps];
+            } else if constexpr (i < nAll) {
+                if constexpr (i < nQ) {
+                    constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
+                    frag[i % kFragRing] = lds_read16(smem, kbuf * G::kTileBytes + kb * 32u * G::kRowBytes + k_rd_row +
+                                                               (((2u * ks + h) ^ k_rd_swz) << 4));
+                } else {
+                    constexpr int j = i - nQ, db = j / 4, ks = j % 4;
+                    u32x4 vf;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const u32x2 half = lds_read_tr8(
+                            smem, vbuf * G::kTileBytes + v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
+                        vf[2 * jj] = half[0];
+                        vf[2 * jj + 1] = half[1];
+                    }
+                    frag[i % kFragRing] = vf;
+                }
+            }
+        };
+        auto issue_mfma = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (kAblate == 2) {   // timing ablation: no MFMA (operands kept alive)
+                keep_alive(frag[i % kFragRing]);
+            } else if constexpr (i < nQ) {
+                constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
+                s_nxt[kb] = T::mfma32(frag[i % kFragRing], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
+            } else {
+                constexpr int j = i - nQ, db = j / 4, ks = j % 4;
+                o[db] = T::mfma32(frag[i % kFragRing], pk_prev[ks], o[db]);
+            }
+        };
+
+        // VALU pair-steps, skewed so that nothing waits on the instruction before it:
+        //   step j:  fma of pair j+2, exp of pair j+1, pack + row-sum of pair j,
+        //            and (last six steps) three max chains over S(t+1).
+        const float neg_m = -m_ref;
+        float ls0 = 0.0f, ls1 = 0.0f, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
+        auto fma_pair = [&](auto jc) {
+            constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;
+            s_cur[e0 >> 4][e0 & 15] = __builtin_fmaf(s_cur[e0 >> 4][e0 & 15], c, neg_m);
+            s_cur[e1 >> 4][e1 & 15] = __builtin_fmaf(s_cur[e1 >> 4][e1 & 15], c, neg_m);
+        };
+        auto exp_pair = [&](auto jc) {
+            constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;
+            s_cur[e0 >> 4][e0 & 15] = fast_exp2(s_cur[e0 >> 4][e0 & 15]);
+            s_cur[e1 >> 4][e1 & 15] = fast_exp2(s_cur[e1 >> 4][e1 & 15]);
+        };
+        auto fin_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, e0 = 2 * j, e1 = e0 + 1;
+            pk_cur[j >> 2][j & 3] = T::pack2(s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]);
+            ls0 += s_cur[e0 >> 4][e0 & 15];
+            ls1 += s_cur[e1 >> 4][e1 & 15];
+        };
+        // The max chains read S(t+1) inside the slot sequence only when every QK^T MFMA has been
+        // issued before the first of those steps (steady iterations); otherwise after the slots.
+        constexpr bool kMaxInSlots = kHasNext && kHasPrev && ((kSteps - 6) * nAll / kSteps >= nQ);
+        auto max_step = [&](auto kc) {   // 6 scores of S(t+1), three independent chains
+            constexpr int e0 = 6 * decltype(kc)::value;
+            constexpr int a0 = e0 < 32 ? e0 : 31, a1 = e0 + 1 < 32 ? e0 + 1 : 31, a2 = e0 + 2 < 32 ? e0 + 2 : 31;
+            constexpr int a3 = e0 + 3 < 32 ? e0 + 3 : 31, a4 = e0 + 4 < 32 ? e0 + 4 : 31, a5 = e0 + 5 < 32 ? e0 + 5 : 31;
+            mx0 = max3(mx0, s_nxt[a0 >> 4][a0 & 15], s_nxt[a1 >> 4][a1 & 15]);
+            mx1 = max3(mx1, s_nxt[a2 >> 4][a2 & 15], s_nxt[a3 >> 4][a3 & 15]);
+            mx2 = max3(mx2, s_nxt[a4 >> 4][a4 & 15], s_nxt[a5 >> 4][a5 & 15]);
+        };
+        auto valu_step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (kAblate == 3) {   // timing ablation: no softmax VALU
+                pk_cur[j >> 2][j & 3] = __builtin_bit_cast(unsigned, s_cur[(2 * j) >> 4][(2 * j) & 15]);
+                return;
+            }
+            if constexpr (j + 2 < kSteps) fma_pair(std::integral_constant<int, j + 2>{});
+            if constexpr (j + 1 < kSteps) exp_pair(std::integral_constant<int, j + 1>{});
+            fin_pair(jc);
+            if constexpr (kMaxInSlots && j >= kSteps - 6) max_step(std::integral_constant<int, j - (kSteps - 6)>{});
+        };
+
+        // ---- the slots -------------------------------------------------------------------------
+        static_for<kReadAhead>([&](auto ic) { issue_reads(ic); });
+        fma_pair(std::integral_constant<int, 0>{});
+        fma_pair(std::integral_constant<int, 1>{});
+        exp_pair(std::integral_constant<int, 0>{});
+        if constexpr (nAll == 0) {
+            static_for<kSteps>([&](auto jc) { valu_step(jc); });
+        } else {
+            static_for<nAll>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i == kStageSlot && kAblate != 4) {
+                    // land the staged tiles mid-iteration: the loads were issued at the top, and the
+                    // LDS writes are long complete when the iteration reaches its barrier
+                    write_k((unsigned)t & 1u);   // K(t+2) -> slot t&1 (held K(t), last read in iteration t-1)
+                    write_v((unsigned)t & 1u);   // V(t)   -> slot t&1 (held V(t-2), last read in iteration t-1)
+                }
+                issue_mfma(ic);
+                issue_reads(std::integral_constant<int, i + kReadAhead>{});
+                // VALU steps [i*kSteps/nAll, (i+1)*kSteps/nAll)
+                constexpr int j0 = i * kSteps / nAll, j1 = (i + 1) * kSteps / nAll;
+                static_for<j1 - j0>([&](auto dj) { valu_step(std::integral_constant<int, j0 + decltype(dj)::value>{}); });
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        l_part += ls0 + ls1;
+
+        if constexpr (kHasNext) {
+            if constexpr (!kMaxInSlots) static_for<6>([&](auto kc) { max_step(kc); });
+            if (mask_next) {   // only ever true in a peeled iteration
+                mask_tail(t + 1, s_nxt);
+                mx0 = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 32; ++e) mx0 = fmaxf(mx0, s_nxt[e >> 4][e & 15]);
+                mx1 = mx2 = mx0;
+            }
+            const float tmax = max3(mx0, mx1, mx2) * c;
+            if (__any(tmax - m_ref > kThr)) rescale(tmax, pk_cur);
+        }
+        stamp(tm_c);
+        if constexpr (kAblate != 4 && nAll == 0) {
+            write_k((unsigned)t & 1u);
+            write_v((unsigned)t & 1u);
+        }
+        if constexpr (kDiag) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(tm_w);
+        __syncthreads();
+        stamp(tm_b);
+    };
+
+    // ---- prologue: K(0), K(1) into LDS; S(0) and the exact row max of tile 0 ---------------------
+    f32x16 sA[2], sB[2];
+    u32x4 pkA[4], pkB[4];
+    load_k(0);
+    write_k(0);
+    load_k(1);
+    write_k(1);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < G::kKSteps; ++ks) {
+            const u32x4 kf = lds_read16(smem, kb * 32u * G::kRowBytes + k_rd_row + (((2u * ks + h) ^ k_rd_swz) << 4));
+            sA[kb] = T::mfma32(kf, qf[ks], ks == 0 ? zero16 : sA[kb]);
+        }
+    if (ntiles == 1 && partial) mask_tail(0, sA);
+    {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) tmax = fmaxf(tmax, sA[e >> 4][e & 15]);
+        tmax *= c;
+        m_ref = fmaxf(tmax, swap_halves(tmax));
+    }
+    __syncthreads();   // all waves are done reading K(0) before iteration 0 overwrites its slot
+
+    const std::true_type yes{};
+    const std::false_type no{};
+    {
+        unsigned long long dummy = 0;
+        stamp(dummy);
+    }
+    if (ntiles == 1) {
+        iter(no, no, 0, false, sA, sB, pkB, pkA);
+    } else {
+        iter(no, yes, 0, partial && ntiles == 2, sA, sB, pkB, pkA);   // now: S in sB, P(0) in pkA
+        // steady iterations t in [1, t_end): the next tile is full, no masking
+        const int t_end = partial ? ntiles - 2 : ntiles - 1;
+        int t = 1;
+        for (; t + 1 < t_end; t += 2) {
+            iter(yes, yes, t, false, sB, sA, pkA, pkB);
+            iter(yes, yes, t + 1, false, sA, sB, pkB, pkA);
+        }
+        // leftovers in canonical naming (scores in sB, previous P in pkA), copying back each time
+        for (; t + 1 < ntiles; ++t) {
+            iter(yes, yes, t, partial && (t + 2 == ntiles), sB, sA, pkA, pkB);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sB[kb] = sA[kb];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
+        }
+        iter(yes, no, ntiles - 1, false, sB, sA, pkA, pkB);   // last tile: P in pkB
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
+    }
+    if constexpr (kDiag) {
+        if (lane == 0 && diag) {
+            unsigned long long* dd = diag + ((size_t)bid * W + wave) * 4;
+            dd[0] = tm_c;
+            dd[1] = tm_w;
+            dd[2] = tm_b;
+            dd[3] = (unsigned long long)ntiles;
+        }
+    }
+    // ---- drain: O^T += V(last)^T.P(last)^T  (P in pkA; V(last) landed at the end of the last iteration)
+    {
+        const unsigned vbuf = (unsigned)(ntiles - 1) & 1u;
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 vf;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const u32x2 half = lds_read_tr8(
+                        smem, vbuf * G::kTileBytes + v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
+                    vf[2 * jj] = half[0];
+                    vf[2 * jj + 1] = half[1];
+                }
+                o[db] = T::mfma32(vf, pkA[ks], o[db]);
+            }
+    }
+
+    // ---- normalise and store: lane holds O[q_row][db*32 + 8g + 4h + 0..3] in o[db][4g..4g+3] ---
+    const float l = l_part + swap_halves(l_part);
+    const float inv = 1.0f / l;
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+#pragma unroll
+    for (int db = 0; db < G::kDBlocks; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned col = db * 32u + 8u * g + 4u * h;
+            const float a = o[db][4 * g] * inv, b = o[db][4 * g + 1] * inv;
+            const float cc = o[db][4 * g + 2] * inv, d = o[db][4 * g + 3] * inv;
+            if constexpr (kOutF32) {
+                const f32x4 v = {a, b, cc, d};
+                buf_store16(ro, (q_row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+            } else {
+                const u32x2 v = {T::pack2(a, b), T::pack2(cc, d)};
+                buf_store8(ro, (q_row * D + col) * 2u, v);
+            }
+        }
+    }
+}
+
+template <typename T, int D, bool kOutF32, int W>
+static hipError_t launch_il(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, float scale, hipStream_t stream)
+{
+    using G = TileGeom<D>;
+    auto kern = fa_fwd_il_kernel<T, D, kOutF32, W>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+    if (e != hipSuccess) return e;
+    const int nqb = (N + 32 * W - 1) / (32 * W);
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * W), G::kLdsBytes, stream,
+                       static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                       static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e,
+                       static_cast<unsigned long long*>(nullptr));
+    return hipGetLastError();
+}
+
+// Diagnostic launch (fp16, d=64, fp32 out): diag[nwg][W][4].
+hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream)
+{
+    using G = TileGeom<64>;
+    if (waves >= 10) {   // 8-wave workgroups with one piece of the iteration removed (timing only, wrong results)
+        const int nqb = (N + 255) / 256;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
+                               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+        };
+        switch (waves - 10) {
+            case 1: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 1>); break;
+            case 2: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 2>); break;
+            case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 3>); break;
+            case 4: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 4>); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (waves == 8) {
+        const int nqb = (N + 255) / 256;
+        hipLaunchKernelGGL((fa_fwd_il_kernel<F16, 64, true, 8, true>), dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
+                           static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                           static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+    } else {
+        const int nqb = (N + 127) / 128;
+        hipLaunchKernelGGL((fa_fwd_il_kernel<F16, 64, true, 4, true>), dim3((unsigned)(BH * nqb)), dim3(256), G::kLdsBytes, stream,
+                           static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                           static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+    }
+    return hipGetLastError();
+}
+
+// waves: 8 = one 256-row workgroup per CU, 4 = two 128-row workgroups per CU
+hipError_t il_dispatch(const void* Q, const void* K, const void* V, void* O,
+                       int BH, int N, int D, float scale, int in_dtype, int out_dtype, int waves,
+                       hipStream_t stream)
+{
+    if (D != 64) return hipErrorInvalidValue;
+    if (waves == 8) {
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_il<F16, 64, true, 8>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_il<F16, 64, false, 8>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_il<BF16, 64, true, 8>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_il<BF16, 64, false, 8>(Q, K, V, O, BH, N, scale, stream);
+    }
+    if (in_dtype == 0)
+        return out_dtype == 0 ? launch_il<F16, 64, true, 4>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_il<F16, 64, false, 4>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_il<BF16, 64, true, 4>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_il<BF16, 64, false, 4>(Q, K, V, O, BH, N, scale, stream);
+}
+
+}  // namespace fa

@@ -27,39 +27,9 @@
 //     [4 keys][32 cols] blocks so each half-wave's transposed read covers all 64 banks once.
 //   * buffer_load/buffer_store with a per-head resource descriptor give N-tail handling for free
 //     (rows >= N read 0 / are not stored); keys >= N are masked to -inf in the last tile only.
-#include "fa_common.hpp"
+#include "fa_tile.hpp"
 
 namespace fa {
-
-constexpr int kWaves  = 8;
-constexpr int kBlockM = 32 * kWaves;   // query rows per workgroup
-constexpr int kBlockN = 64;            // keys per tile
-constexpr float kThr  = 8.0f;          // lazy-rescale threshold, log2 domain (P <= 2^8 fits fp16)
-
-template <int D> struct TileGeom {
-    static constexpr int kRowBytes  = D * 2;
-    static constexpr int kChunks    = D / 8;                 // 16-B chunks per row
-    static constexpr int kTileBytes = kBlockN * kRowBytes;   // one K (or V) tile
-    static constexpr int kBufBytes  = 2 * kTileBytes;        // K + V
-    static constexpr int kLdsBytes  = 2 * kBufBytes;         // double buffered
-    static constexpr int kLoads     = (kBlockN * kChunks) / (64 * kWaves);  // 16-B loads / thread / tile
-    static constexpr int kKSteps    = D / 16;                // MFMA k-steps over d
-    static constexpr int kDBlocks   = D / 32;                // 32-row blocks of O^T
-    // K image: row-major rows of D*2 bytes, 16-B chunk index XORed with a row-derived value so
-    // that the 16 lanes of a ds_read_b128 group (16 different rows, same chunk) hit 16 slots.
-    static __device__ __forceinline__ unsigned k_swz(unsigned row) {
-        return D == 64 ? ((row >> 1) & 7u) : (row & 15u);
-    }
-    static __device__ __forceinline__ unsigned k_off(unsigned row, unsigned chunk) {
-        return row * kRowBytes + ((chunk ^ k_swz(row)) << 4);
-    }
-    // V image: [key/4][d/32] blocks of 256 B, inside a block [key%4][32 cols] (64-B rows).  The
-    // 64-B row slot is rotated by the column block so a row's 16-B chunk writes spread over banks.
-    static __device__ __forceinline__ unsigned v_off(unsigned key, unsigned chunk) {
-        const unsigned dblk = chunk >> 2;
-        return ((key >> 2) * kDBlocks + dblk) * 256u + (((key & 3u) ^ (dblk & 1u)) << 6) + ((chunk & 3u) << 4);
-    }
-};
 
 template <typename T, int D, bool kOutF32>
 __global__ __launch_bounds__(64 * kWaves, 2)
@@ -433,14 +403,33 @@ static hipError_t dispatch_d(const void* Q, const void* K, const void* V, void* 
     return launch_generic<T, kOutF32>(Q, K, V, O, BH, N, D, scale, stream);
 }
 
-// algo: 0 auto, 1 generic single-fragment kernel, 2 tiled kernel (D in {64,128} only)
+hipError_t pipe_dispatch(const void* Q, const void* K, const void* V, void* O,
+                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                         hipStream_t stream);
+
+hipError_t pp_dispatch(const void* Q, const void* K, const void* V, void* O,
+                       int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                       hipStream_t stream);
+
+hipError_t il_dispatch(const void* Q, const void* K, const void* V, void* O,
+                       int BH, int N, int D, float scale, int in_dtype, int out_dtype, int waves,
+                       hipStream_t stream);
+
+// algo: 0 auto, 1 generic single-fragment kernel, 2 tiled kernel (D in {64,128} only),
+//       3 software-pipelined tiled kernel (D = 64 only), 4 ping-pong tiled kernel (D in {64,128})
 hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                             int algo, hipStream_t stream)
 {
     if (!Q || !K || !V || !O) return hipErrorInvalidValue;
     if (BH <= 0 || N <= 0 || D <= 0 || D % 16 != 0 || D > kGenMaxD) return hipErrorInvalidValue;
-    if ((unsigned long long)N * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;  // per-head 32-bit offsets
+    // per-head byte offsets are 32 bit, including the rows a partial last query block overhangs
+    if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
+    if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 5) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 8, stream);
+    if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
                               : dispatch_d<F16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);

@@ -30,6 +30,10 @@ extern "C" {
 #define FA_ALGO_AUTO    0
 #define FA_ALGO_GENERIC 1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED   2 /* LDS-staged 256-row workgroups, D in {64,128} */
+#define FA_ALGO_PIPE    3 /* the same, software-pipelined (QK^T of tile t+1 under softmax of tile t), D = 64 */
+#define FA_ALGO_INTERLEAVED 5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
+#define FA_ALGO_INTERLEAVED_2WG 6 /* the same with 128-row workgroups, two per CU */
+#define FA_ALGO_PINGPONG 4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
 
 /* General-shape forward.  Replaces
  *   flashattn_forward_wmma_kernel(const half* Q, const half* K, const half* V, float* O,

@@ -41,7 +41,7 @@ def _run(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False, scale=None):
 
 
 def _algos_for(d):
-    return (0, 1, 2) if d in (64, 128) else (0, 1)
+    return (0, 1, 2, 3, 4, 5, 6) if d == 64 else ((0, 1, 2, 4) if d == 128 else (0, 1))
 
 
 def _check(oracle, got, want, fmt, what, out_same=False):
@@ -135,7 +135,7 @@ def test_forced_rescale_branch(fa, oracle, torch_cuda, fmt, d):
     jumps = (np.diff(run_max, axis=-1) > 8.0).sum()
     assert jumps > 50, "input does not force the rescale branch"
     want = oracle.forward(q, k, v, accum=1, nthreads=8)
-    for algo in (0, 1):
+    for algo in _algos_for(d):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"forced rescale d={d} fmt={fmt} algo={algo}")
 
