@@ -110,8 +110,9 @@ def main():
                        "B_per_gpu": B, "H": H, "N": N, "d": d, "flops_per_step_per_gpu": flops_per_gpu},
             "pct_mfma_peak": round(100.0 * value / (PEAK_TFLOPS * world), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "fa_fwd_kernel", "avg_launch_ms": round(kern_ms, 5),
+                         "frac": round(achieved / PEAK_TFLOPS, 4),
+                         "traffic": measured_traffic(B, H, N, d, args.dtype, args.out),
+                         "kernel": "fa::fa_fwd_il_kernel" if d == 64 else "fa::fa_fwd_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "algorithmic_bytes": fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2),
                          "hbm_GBps_algorithmic": round(fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2)
                                                        / (kern_ms * 1e-3) / 1e9, 1)},
@@ -121,26 +122,76 @@ def main():
     ranks.close()
 
 
+def cpu_threads():
+    """Threads for the CPU baseline: this process's CPU share, capped at 16 (one GPU's share of the box)."""
+    env = os.environ.get("FA_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(q, k, v, o_gpu, N, d, budget_s):
     """The oracle (naive 3-loop fp32 C port of the reference's CPU function) on a bounded sample
-    of the same workload: whole query-row ranges of head (0,0), all N keys, all host cores.
-    Also cross-checks the GPU output on that sample (the oracle is the checker, never the path)."""
+    of the same workload: whole heads (all N query rows x all N keys) starting at (b=0,h=0), or a
+    row range of head 0 when one head exceeds the budget.  Also cross-checks the GPU output on
+    that sample (the oracle is the checker here, never the measured path)."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
-    qs, ks, vs = (t[0, 0].float().cpu().numpy()[None] for t in (q, k, v))
+    threads = cpu_threads()
+    H = q.shape[1]
     flops_row = 4.0 * N * d
+    q0, k0, v0 = (t[0, 0].float().cpu().numpy()[None] for t in (q, k, v))
+    cal_rows = min(N, 8 * threads)
     t0 = time.perf_counter()
-    orc.forward(qs, ks, vs, accum=0, nthreads=cores, row_range=(0, 2 * cores))
-    cal = max(time.perf_counter() - t0, 1e-4)
-    rows = int(min(N, max(4 * cores, (budget_s / cal) * 2 * cores)))
-    t0 = time.perf_counter()
-    want = orc.forward(qs, ks, vs, accum=0, nthreads=cores, row_range=(0, rows))
-    dt_ = time.perf_counter() - t0
-    err = orc.max_abs(o_gpu[0, 0, :rows].float().cpu().numpy(), want[0, :rows])
-    return {"value": round(rows * flops_row / dt_ / 1e12, 6), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"{rows} query rows x {N} keys of head (b=0,h=0), d={d}, {dt_:.2f} s on {cores} threads "
-                      f"(naive 3-loop fp32, OpenMP over rows)",
+    orc.forward(q0, k0, v0, accum=0, nthreads=threads, row_range=(0, cal_rows))
+    rate = cal_rows / max(time.perf_counter() - t0, 1e-5)          # rows / s
+    heads = int(budget_s * rate / N)
+    if heads >= 1:
+        heads = min(heads, q.shape[0] * H, 64)
+        idx = [(i // H, i % H) for i in range(heads)]
+        qs, ks, vs = (torch_stack(t, idx) for t in (q, k, v))
+        t0 = time.perf_counter()
+        want = orc.forward(qs, ks, vs, accum=0, nthreads=threads)
+        dt_ = time.perf_counter() - t0
+        got = torch_stack(o_gpu, idx)
+        rows = heads * N
+        what = f"{heads} whole (b,h) heads x {N} query rows x {N} keys"
+    else:
+        rows = max(threads, int(budget_s * rate))
+        t0 = time.perf_counter()
+        want = orc.forward(q0, k0, v0, accum=0, nthreads=threads, row_range=(0, rows))[:, :rows]
+        dt_ = time.perf_counter() - t0
+        got = o_gpu[0, 0, :rows].float().cpu().numpy()[None]
+        what = f"{rows} query rows x {N} keys of head (b=0,h=0)"
+    err = orc.max_abs(got, want)
+    return {"value": round(rows * flops_row / dt_ / 1e12, 6), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"{what}, d={d}: {rows * flops_row / 1e9:.1f} GFLOP in {dt_:.2f} s on {threads} threads "
+                      f"(oracle/attention_cpu.c, naive 3-loop fp32, OpenMP over rows)",
             "gpu_vs_cpu_max_abs_on_sample": float(err)}
+
+
+def torch_stack(t, idx):
+    import numpy as np
+    return np.stack([t[b, h].float().cpu().numpy() for (b, h) in idx])
+
+
+def measured_traffic(B, H, N, d, dtype, out):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
+    written by tools/collect_profiles.sh with the gfx950 FETCH_SIZE x2 correction), if they were
+    taken on this exact workload; else None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        cfg = rec.get("config", {})
+        if (cfg.get("B"), cfg.get("H"), cfg.get("N"), cfg.get("d"), cfg.get("dtype"), cfg.get("out")) == (B, H, N, d, dtype, out):
+            return rec.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 if __name__ == "__main__":

@@ -232,6 +232,18 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             constexpr int i = decltype(ic)::value;
             if constexpr (kAblate == 2) {   // timing ablation: no MFMA (operands kept alive)
                 keep_alive(frag[i % kFragRing]);
+            } else if constexpr (kAblate == 5) {   // timing ablation: reads issued, MFMA does not wait for them
+                if constexpr (i < nQ) {
+                    constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
+                    s_nxt[kb] = T::mfma32(qf[(ks + 1) % G::kKSteps], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
+                } else {
+                    constexpr int j = i - nQ, db = j / 4, ks = j % 4;
+                    o[db] = T::mfma32(qf[ks], pk_prev[ks], o[db]);
+                }
+                if constexpr (i + 1 == nAll) {
+#pragma unroll
+                    for (int f = 0; f < kFragRing; ++f) keep_alive(frag[f]);
+                }
             } else if constexpr (i < nQ) {
                 constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
                 s_nxt[kb] = T::mfma32(frag[i % kFragRing], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
@@ -331,7 +343,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         }
         if constexpr (kDiag) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stamp(tm_w);
-        __syncthreads();
+        if constexpr (kAblate != 6) __syncthreads();
         stamp(tm_b);
     };
 
@@ -477,6 +489,8 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
             case 2: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 2>); break;
             case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 3>); break;
             case 4: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 4>); break;
+            case 5: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 5>); break;
+            case 6: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 6>); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

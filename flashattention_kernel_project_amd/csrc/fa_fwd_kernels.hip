@@ -31,8 +31,11 @@
 
 namespace fa {
 
-template <typename T, int D, bool kOutF32>
-__global__ __launch_bounds__(64 * kWaves, 2)
+// W = waves per workgroup (32 query rows each), kOcc = workgroups' waves per SIMD the register
+// budget is held to (W = 8, kOcc = 2: one 256-row workgroup per CU; W = 4, kOcc = 3: three
+// independent 128-row workgroups per CU, so the waves sharing a SIMD are never barrier-coupled).
+template <typename T, int D, bool kOutF32, int W = kWaves, int kOcc = 2>
+__global__ __launch_bounds__(64 * W, kOcc)
 void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                    const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                    int N, int nqb, float scale_log2e)
@@ -58,7 +61,8 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
 
-    const unsigned q_row = qb * kBlockM + wave * 32u + r;
+    constexpr int kLoadsW = (kBlockN * G::kChunks) / (64 * W);
+    const unsigned q_row = qb * (32u * W) + wave * 32u + r;
 
     // ---- Q^T fragments (B operand of S^T = K.Q^T), resident for the whole kernel ---------------
     // c = |scale|*log2(e) is applied to the fp32 scores; a negative scale flips Q's sign bits so
@@ -75,26 +79,26 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
     }
 
     // ---- staging: each thread moves kLoads 16-B chunks of K and of V per tile -----------------
-    unsigned g_off[G::kLoads], k_lds[G::kLoads], v_lds[G::kLoads];
+    unsigned g_off[kLoadsW], k_lds[kLoadsW], v_lds[kLoadsW];
 #pragma unroll
-    for (int p = 0; p < G::kLoads; ++p) {
-        const unsigned idx = tid + p * 64u * kWaves;
+    for (int p = 0; p < kLoadsW; ++p) {
+        const unsigned idx = tid + p * 64u * W;
         const unsigned row = idx / G::kChunks, c = idx % G::kChunks;
         g_off[p] = row * G::kRowBytes + c * 16u;
         k_lds[p] = G::k_off(row, c);
         v_lds[p] = G::kTileBytes + G::v_off(row, c);
     }
-    u32x4 kst[G::kLoads], vst[G::kLoads];
+    u32x4 kst[kLoadsW], vst[kLoadsW];
     auto stage_load = [&](unsigned kv0) {
 #pragma unroll
-        for (int p = 0; p < G::kLoads; ++p) {
+        for (int p = 0; p < kLoadsW; ++p) {
             kst[p] = buf_load16(rk, kv0 * G::kRowBytes + g_off[p]);
             vst[p] = buf_load16(rv, kv0 * G::kRowBytes + g_off[p]);
         }
     };
     auto stage_write = [&](unsigned buf) {
 #pragma unroll
-        for (int p = 0; p < G::kLoads; ++p) {
+        for (int p = 0; p < kLoadsW; ++p) {
             lds_write16(smem, buf * G::kBufBytes + k_lds[p], kst[p]);
             lds_write16(smem, buf * G::kBufBytes + v_lds[p], vst[p]);
         }
@@ -356,12 +360,12 @@ void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
 // ---------------------------------------------------------------------------------------------
 namespace fa {
 
-template <typename T, int D, bool kOutF32>
+template <typename T, int D, bool kOutF32, int W = kWaves, int kOcc = 2>
 static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void* O,
                                int BH, int N, float scale, hipStream_t stream)
 {
     using G = TileGeom<D>;
-    auto kern = fa_fwd_kernel<T, D, kOutF32>;
+    auto kern = fa_fwd_kernel<T, D, kOutF32, W, kOcc>;
     static bool attr_set = false;   // dyn-LDS opt-in is per function, cached (SURVEY 8(b) "Ownership")
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -369,10 +373,10 @@ static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nqb = (N + kBlockM - 1) / kBlockM;
+    const int nqb = (N + 32 * W - 1) / (32 * W);
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * kWaves), G::kLdsBytes, stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * W), G::kLdsBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e);
     return hipGetLastError();
@@ -426,8 +430,19 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     // per-head byte offsets are 32 bit, including the rows a partial last query block overhangs
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
+    if (algo == 0 && D == 64) {
+        // d = 64: the interleaved kernel.  256-row workgroups (one per CU) when they fill the chip at
+        // least twice over, else 128-row workgroups (two per CU) for twice the parallelism.
+        const long long nwg256 = (long long)BH * ((N + 255) / 256);
+        return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, nwg256 >= 512 ? 8 : 4, stream);
+    }
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 7 || algo == 8) {   // experimental occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out
+        if (D != 64 || in_dtype != 0 || out_dtype != 0) return hipErrorInvalidValue;
+        return algo == 7 ? launch_tiled<F16, 64, true, 4, 3>(Q, K, V, O, BH, N, scale, stream)
+                         : launch_tiled<F16, 64, true, 4, 2>(Q, K, V, O, BH, N, scale, stream);
+    }
     if (algo == 5) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 8, stream);
     if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (in_dtype == 0)

@@ -19,6 +19,9 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     h8 af, bf;
     for (int i = 0; i < 8; ++i) { af[i] = (_Float16)(a + i); bf[i] = (_Float16)(b - i); }
     f16v acc16 = {0};
+    f16v accs[4] = {};
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v acc4[4] = {};
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) char lds[16384];
@@ -112,6 +115,14 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
             REP16(X)
 #undef X
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (KIND == 21) {   // MFMA, 4 independent accumulators
+#define X(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accs[(i) & 3]) : "v"(af), "v"(bf));
+            REP16(X)
+#undef X
+        } else if constexpr (KIND == 22) {   // MFMA 16x16x32, 4 independent accumulators
+#define X(i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[(i) & 3]) : "v"(af), "v"(bf));
+            REP16(X)
+#undef X
         } else if constexpr (KIND == 13) {  // v_exp_f32 interleaved 1:1 with independent v_fma (co-issue test)
 #define X(i) asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %1, %1, %2, %3" : "+v"(x[i & 7]), "+v"(x[8 + (i & 7)]) : "v"(a), "v"(b));
             REP16(X) REP16(X)
@@ -125,7 +136,8 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     for (int i = 0; i < 16; ++i) acc += x[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc += (float)y[i];
-    for (int i = 0; i < 16; ++i) acc += acc16[i];
+    for (int i = 0; i < 16; ++i) acc += acc16[i] + accs[0][i] + accs[1][i] + accs[2][i] + accs[3][i];
+    for (int i = 0; i < 4; ++i) acc += acc4[0][i] + acc4[1][i] + acc4[2][i] + acc4[3][i];
     for (int i = 0; i < 4; ++i) acc += (float)ld[i][0];
     for (int i = 0; i < 8; ++i) acc += (float)ld2[i][0];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
@@ -179,6 +191,8 @@ int main()
     run<14>("slot: 1 MFMA32x32x16 + 8 VALU  (per slot)", 16);
     run<15>("slot: 8 VALU only              (per slot)", 16);
     run<16>("slot: 1 MFMA only              (per slot)", 16);
+    run<21>("MFMA 32x32x16 f16, 4 independent accumulators", 16);
+    run<22>("MFMA 16x16x32 f16, 4 independent accumulators", 16);
     run<17>("slot: MFMA + 2 ds_read_tr_b64 + 8 VALU", 16);
     run<18>("slot: MFMA + 1 ds_read_b128 + 8 VALU", 16);
     run<19>("slot: 2 ds_read_tr_b64 only", 16);
