@@ -11,6 +11,7 @@ namespace fa {
 
 typedef float    f32x16 __attribute__((ext_vector_type(16)));
 typedef float    f32x4  __attribute__((ext_vector_type(4)));
+typedef float    f32x2  __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4  __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2  __attribute__((ext_vector_type(2)));
 typedef short    s16x4  __attribute__((ext_vector_type(4)));
@@ -47,6 +48,7 @@ struct F16 {
     static __device__ __forceinline__ float one(uint16_t b) {
         return (float)__builtin_bit_cast(_Float16, b);
     }
+    static constexpr unsigned kOnes2 = 0x3C003C00u;   // two 1.0 halves
 };
 
 struct BF16 {
@@ -66,6 +68,7 @@ struct BF16 {
     static __device__ __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
     static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
     static __device__ __forceinline__ float one(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+    static constexpr unsigned kOnes2 = 0x3F803F80u;   // two 1.0 bfloat16
 };
 
 // ---- buffer resources (wave-uniform base + byte count; out-of-range loads read 0, stores drop) --

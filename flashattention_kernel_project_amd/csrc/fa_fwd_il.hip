@@ -20,6 +20,11 @@
 // (rare, wave-uniform branch at the end of the iteration) rescales O, l and the packed P(t) that
 // has not been multiplied into O yet.
 //
+// The vector pipe is the bottleneck at d=64 (rocprofv3: VALU-active 64-72 % of SIMD time, MFMA 41 %), so
+// vector instructions are traded for matrix ones where possible: the row sums l = sum_k P come out
+// of four extra MFMAs per tile against an all-ones A fragment (no LDS traffic; every lane then holds
+// the complete row sum of its query, no cross-half exchange), and c*S - m is a packed v_pk_fma_f32.
+//
 // K(t+2) and V(t) are fetched HBM/L2 -> registers at the top of iteration t and written to LDS at
 // its end (2-deep rings for K and V, one barrier per iteration): the role of the reference's
 // loader warp + cp.async ping-pong (flashattn_streaming_16x16_mw_v10.cu:156-195,
@@ -154,13 +159,14 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
     float m_ref = 0.0f;    // reference max of this lane's query row, log2 units (c*S)
-    float l_part = 0.0f;   // this half-wave's share of the row sum
+    f32x16 o_l = zero16;   // row sums: accumulator of ones(32x16).P^T, every register = l of this lane's row
+    const u32x4 ones = {T::kOnes2, T::kOnes2, T::kOnes2, T::kOnes2};
 
     const int ntiles = (N + kBlockN - 1) / kBlockN;
     const bool partial = (N % kBlockN) != 0;
 
     constexpr int nQK = 2 * G::kKSteps;   // MFMAs of S(t+1) = K.Q^T
-    constexpr int nPV = 4 * G::kDBlocks;  // MFMAs of O^T += V^T.P^T
+    constexpr int nPV = 4 * (G::kDBlocks + 1);  // MFMAs of O^T += V^T.P^T plus the row-sum block (A = ones)
 
     auto keep_alive = [&](u32x4& v) { asm volatile("" : "+v"(v)); };
     auto mask_tail = [&](int tile, f32x16 (&s)[2]) {   // keys >= N -> -inf (p = 0)
@@ -181,7 +187,8 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         for (int db = 0; db < G::kDBlocks; ++db)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-        l_part *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_l[i] *= alpha;
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)   // P(t) is still waiting for its PV: bring it to the new scale too
 #pragma unroll
@@ -190,7 +197,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 
     // One iteration.  s_cur: raw S(t), overwritten by P(t); s_nxt: receives raw S(t+1);
     // pk_prev: packed P(t-1) (consumed by PV); pk_cur: receives packed P(t).
-    auto iter = [&](auto has_prev_c, auto has_next_c, int t, bool mask_next,
+    auto iter = [&](auto has_prev_c, auto has_next_c, auto par_c, int t, bool mask_next,
                     f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[4], u32x4 (&pk_cur)[4]) {
         constexpr bool kHasPrev = decltype(has_prev_c)::value;
         constexpr bool kHasNext = decltype(has_next_c)::value;
@@ -203,7 +210,9 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             load_v(t);
         }
 
-        const unsigned kbuf = (unsigned)(t + 1) & 1u, vbuf = (unsigned)(t + 1) & 1u;   // K(t+1), V(t-1)
+        // ring slot of K(t+1) and of V(t-1): (t+1)&1, a compile-time constant in the unrolled steady loop
+        constexpr int kPar = decltype(par_c)::value;
+        const unsigned kbuf = kPar >= 0 ? (unsigned)kPar : ((unsigned)(t + 1) & 1u), vbuf = kbuf;
         u32x4 frag[kFragRing];
         auto issue_reads = [&](auto ic) {   // LDS operand reads of MFMA ic
             constexpr int i = decltype(ic)::value;
@@ -214,7 +223,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                     constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
                     frag[i % kFragRing] = lds_read16(smem, kbuf * G::kTileBytes + kb * 32u * G::kRowBytes + k_rd_row +
                                                                (((2u * ks + h) ^ k_rd_swz) << 4));
-                } else {
+                } else if constexpr ((i - nQ) / 4 < G::kDBlocks) {
                     constexpr int j = i - nQ, db = j / 4, ks = j % 4;
                     u32x4 vf;
 #pragma unroll
@@ -236,9 +245,11 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                 if constexpr (i < nQ) {
                     constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
                     s_nxt[kb] = T::mfma32(qf[(ks + 1) % G::kKSteps], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
-                } else {
+                } else if constexpr ((i - nQ) / 4 < G::kDBlocks) {
                     constexpr int j = i - nQ, db = j / 4, ks = j % 4;
                     o[db] = T::mfma32(qf[ks], pk_prev[ks], o[db]);
+                } else {
+                    o_l = T::mfma32(ones, pk_prev[(i - nQ) % 4], o_l);
                 }
                 if constexpr (i + 1 == nAll) {
 #pragma unroll
@@ -247,9 +258,11 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             } else if constexpr (i < nQ) {
                 constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
                 s_nxt[kb] = T::mfma32(frag[i % kFragRing], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
-            } else {
+            } else if constexpr ((i - nQ) / 4 < G::kDBlocks) {
                 constexpr int j = i - nQ, db = j / 4, ks = j % 4;
                 o[db] = T::mfma32(frag[i % kFragRing], pk_prev[ks], o[db]);
+            } else {
+                o_l = T::mfma32(ones, pk_prev[(i - nQ) % 4], o_l);   // row sums: no LDS operand
             }
         };
 
@@ -257,11 +270,14 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         //   step j:  fma of pair j+2, exp of pair j+1, pack + row-sum of pair j,
         //            and (last six steps) three max chains over S(t+1).
         const float neg_m = -m_ref;
-        float ls0 = 0.0f, ls1 = 0.0f, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
-        auto fma_pair = [&](auto jc) {
+        float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
+        const f32x2 c2 = {c, c}, neg_m2 = {neg_m, neg_m};
+        auto fma_pair = [&](auto jc) {   // one v_pk_fma_f32 for the two scores of the pair
             constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;
-            s_cur[e0 >> 4][e0 & 15] = __builtin_fmaf(s_cur[e0 >> 4][e0 & 15], c, neg_m);
-            s_cur[e1 >> 4][e1 & 15] = __builtin_fmaf(s_cur[e1 >> 4][e1 & 15], c, neg_m);
+            f32x2 x = {s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]};
+            x = __builtin_elementwise_fma(x, c2, neg_m2);
+            s_cur[e0 >> 4][e0 & 15] = x[0];
+            s_cur[e1 >> 4][e1 & 15] = x[1];
         };
         auto exp_pair = [&](auto jc) {
             constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;
@@ -271,8 +287,6 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         auto fin_pair = [&](auto jc) {
             constexpr int j = decltype(jc)::value, e0 = 2 * j, e1 = e0 + 1;
             pk_cur[j >> 2][j & 3] = T::pack2(s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]);
-            ls0 += s_cur[e0 >> 4][e0 & 15];
-            ls1 += s_cur[e1 >> 4][e1 & 15];
         };
         // The max chains read S(t+1) inside the slot sequence only when every QK^T MFMA has been
         // issued before the first of those steps (steady iterations); otherwise after the slots.
@@ -314,15 +328,19 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                     write_k((unsigned)t & 1u);   // K(t+2) -> slot t&1 (held K(t), last read in iteration t-1)
                     write_v((unsigned)t & 1u);   // V(t)   -> slot t&1 (held V(t-2), last read in iteration t-1)
                 }
+                // The SIMD arbitrates between its two waves by age; raising the priority around the
+                // short MFMA + LDS-read issue lets the younger wave feed the long-latency units as
+                // soon as it gets there instead of queueing behind the older wave's VALU stream.
+                __builtin_amdgcn_s_setprio(1);
                 issue_mfma(ic);
                 issue_reads(std::integral_constant<int, i + kReadAhead>{});
+                __builtin_amdgcn_s_setprio(0);
                 // VALU steps [i*kSteps/nAll, (i+1)*kSteps/nAll)
                 constexpr int j0 = i * kSteps / nAll, j1 = (i + 1) * kSteps / nAll;
                 static_for<j1 - j0>([&](auto dj) { valu_step(std::integral_constant<int, j0 + decltype(dj)::value>{}); });
             });
         }
         __builtin_amdgcn_sched_barrier(0);
-        l_part += ls0 + ls1;
 
         if constexpr (kHasNext) {
             if constexpr (!kMaxInSlots) static_for<6>([&](auto kc) { max_step(kc); });
@@ -374,30 +392,31 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 
     const std::true_type yes{};
     const std::false_type no{};
+    const std::integral_constant<int, -1> rt{};   // ring-slot parity known only at run time
     {
         unsigned long long dummy = 0;
         stamp(dummy);
     }
     if (ntiles == 1) {
-        iter(no, no, 0, false, sA, sB, pkB, pkA);
+        iter(no, no, rt, 0, false, sA, sB, pkB, pkA);
     } else {
-        iter(no, yes, 0, partial && ntiles == 2, sA, sB, pkB, pkA);   // now: S in sB, P(0) in pkA
+        iter(no, yes, rt, 0, partial && ntiles == 2, sA, sB, pkB, pkA);   // now: S in sB, P(0) in pkA
         // steady iterations t in [1, t_end): the next tile is full, no masking
         const int t_end = partial ? ntiles - 2 : ntiles - 1;
         int t = 1;
         for (; t + 1 < t_end; t += 2) {
-            iter(yes, yes, t, false, sB, sA, pkA, pkB);
-            iter(yes, yes, t + 1, false, sA, sB, pkB, pkA);
+            iter(yes, yes, std::integral_constant<int, 0>{}, t, false, sB, sA, pkA, pkB);       // t odd
+            iter(yes, yes, std::integral_constant<int, 1>{}, t + 1, false, sA, sB, pkB, pkA);   // t+1 even
         }
         // leftovers in canonical naming (scores in sB, previous P in pkA), copying back each time
         for (; t + 1 < ntiles; ++t) {
-            iter(yes, yes, t, partial && (t + 2 == ntiles), sB, sA, pkA, pkB);
+            iter(yes, yes, rt, t, partial && (t + 2 == ntiles), sB, sA, pkA, pkB);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) sB[kb] = sA[kb];
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
         }
-        iter(yes, no, ntiles - 1, false, sB, sA, pkA, pkB);   // last tile: P in pkB
+        iter(yes, no, rt, ntiles - 1, false, sB, sA, pkA, pkB);   // last tile: P in pkB
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
     }
@@ -427,11 +446,12 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                 }
                 o[db] = T::mfma32(vf, pkA[ks], o[db]);
             }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) o_l = T::mfma32(ones, pkA[ks], o_l);
     }
 
     // ---- normalise and store: lane holds O[q_row][db*32 + 8g + 4h + 0..3] in o[db][4g..4g+3] ---
-    const float l = l_part + swap_halves(l_part);
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / o_l[0];   // every register of o_l holds the full row sum
     constexpr unsigned es = kOutF32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t ro =
         make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
