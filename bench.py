@@ -150,7 +150,7 @@ def cpu_baseline(q, k, v, o_gpu, N, d, budget_s):
     rate = cal_rows / max(time.perf_counter() - t0, 1e-5)          # rows / s
     heads = int(budget_s * rate / N)
     if heads >= 1:
-        heads = min(heads, q.shape[0] * H, 64)
+        heads = min(heads, q.shape[0] * H)
         idx = [(i // H, i % H) for i in range(heads)]
         qs, ks, vs = (torch_stack(t, idx) for t in (q, k, v))
         t0 = time.perf_counter()
