@@ -6,7 +6,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfa_mi355.so")
+LIB_PATH = os.environ.get("FA_MI355_LIB") or os.path.join(_HERE, "libfa_mi355.so")   # override: A/B of experimental builds
 CSRC = os.path.join(_HERE, "csrc")
 
 F16, BF16 = 0, 1

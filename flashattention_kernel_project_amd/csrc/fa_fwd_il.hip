@@ -45,7 +45,19 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-constexpr int kReadAhead = 4;             // LDS operand reads run this many MFMAs ahead
+#ifndef FA_IL_READ_AHEAD
+#define FA_IL_READ_AHEAD 4
+#endif
+#ifndef FA_IL_SETPRIO
+#define FA_IL_SETPRIO 1
+#endif
+#ifndef FA_IL_NO_MAX
+#define FA_IL_NO_MAX 0   // experiment: skip the per-tile row max (UNSAFE: no overflow protection)
+#endif
+#ifndef FA_IL_MFMA_ORDER
+#define FA_IL_MFMA_ORDER 0
+#endif
+constexpr int kReadAhead = FA_IL_READ_AHEAD;             // LDS operand reads run this many MFMAs ahead
 constexpr int kFragRing  = kReadAhead + 1;
 
 // kDiag: diagnostic build only (never the shipped path): per-wave s_memtime sums of the time spent
@@ -62,7 +74,8 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                       const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                       int N, int nqb, float scale_log2e, unsigned long long* __restrict__ diag = nullptr)
 {
-    unsigned long long tm_c = 0, tm_w = 0, tm_b = 0, tm_last = 0;
+    unsigned long long tm_c = 0, tm_w = 0, tm_b = 0, tm_last = 0, tm_entry = 0, tm_loop0 = 0, tm_loop1 = 0;
+    if constexpr (kDiag) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm_entry)::"memory");
     auto stamp = [&](unsigned long long& acc) {
         if constexpr (kDiag) {
             unsigned long long now;
@@ -120,24 +133,27 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         k_lds[p] = G::k_off(row, ch);
         v_lds[p] = 2u * G::kTileBytes + G::v_off(row, ch);
     }
-    u32x4 kst[kLoadsW], vst[kLoadsW];
+    // Two staging register sets: the tiles written to LDS in iteration t were requested in
+    // iteration t-1 (a loaded L2/HBM round trip is ~1250 cycles: the same order as an iteration).
+    struct Stage { u32x4 k[kLoadsW], v[kLoadsW]; };
+    Stage stA, stB;
     // Tiles past the end read zeros through the buffer bounds and land in ring slots nobody
     // reads any more: staging is unconditional and the loop body stays branch-free.
-    auto load_k = [&](int tile) {
+    auto load_k = [&](Stage& st, int tile) {
 #pragma unroll
-        for (int p = 0; p < kLoadsW; ++p) kst[p] = buf_load16(rk, (unsigned)tile * kBlockN * G::kRowBytes + g_off[p]);
+        for (int p = 0; p < kLoadsW; ++p) st.k[p] = buf_load16(rk, (unsigned)tile * kBlockN * G::kRowBytes + g_off[p]);
     };
-    auto load_v = [&](int tile) {
+    auto load_v = [&](Stage& st, int tile) {
 #pragma unroll
-        for (int p = 0; p < kLoadsW; ++p) vst[p] = buf_load16(rv, (unsigned)tile * kBlockN * G::kRowBytes + g_off[p]);
+        for (int p = 0; p < kLoadsW; ++p) st.v[p] = buf_load16(rv, (unsigned)tile * kBlockN * G::kRowBytes + g_off[p]);
     };
-    auto write_k = [&](unsigned buf) {
+    auto write_k = [&](const Stage& st, unsigned buf) {
 #pragma unroll
-        for (int p = 0; p < kLoadsW; ++p) lds_write16(smem, buf * G::kTileBytes + k_lds[p], kst[p]);
+        for (int p = 0; p < kLoadsW; ++p) lds_write16(smem, buf * G::kTileBytes + k_lds[p], st.k[p]);
     };
-    auto write_v = [&](unsigned buf) {
+    auto write_v = [&](const Stage& st, unsigned buf) {
 #pragma unroll
-        for (int p = 0; p < kLoadsW; ++p) lds_write16(smem, buf * G::kTileBytes + v_lds[p], vst[p]);
+        for (int p = 0; p < kLoadsW; ++p) lds_write16(smem, buf * G::kTileBytes + v_lds[p], st.v[p]);
     };
 
     // ---- per-lane LDS read addresses (see fa_fwd_kernels.hip) -----------------------------------
@@ -197,17 +213,19 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 
     // One iteration.  s_cur: raw S(t), overwritten by P(t); s_nxt: receives raw S(t+1);
     // pk_prev: packed P(t-1) (consumed by PV); pk_cur: receives packed P(t).
-    auto iter = [&](auto has_prev_c, auto has_next_c, auto par_c, int t, bool mask_next,
-                    f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[4], u32x4 (&pk_cur)[4]) {
+    auto iter = [&](auto track_c, auto has_prev_c, auto has_next_c, auto par_c, int t, bool mask_next,
+                    f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[4], u32x4 (&pk_cur)[4],
+                    Stage& st_land, Stage& st_fetch) {
+        constexpr bool kTrack = decltype(track_c)::value;   // false: optimistic pass, no running max
         constexpr bool kHasPrev = decltype(has_prev_c)::value;
         constexpr bool kHasNext = decltype(has_next_c)::value;
         constexpr int nQ = kHasNext ? nQK : 0, nP = kHasPrev ? nPV : 0, nAll = nQ + nP;
         constexpr int kSteps = 16;   // VALU pair-steps (2 scores each)
         constexpr int kStageSlot = nAll > 0 ? (3 * nAll) / 4 : -1;   // slot in front of which the staged tiles are written
 
-        if constexpr (kAblate != 4) {
-            load_k(t + 2);
-            load_v(t);
+        if constexpr (!(kAblate & 8)) {
+            load_k(st_fetch, t + 3);   // requested now, landed in LDS during iteration t+1
+            load_v(st_fetch, t + 1);
         }
 
         // ring slot of K(t+1) and of V(t-1): (t+1)&1, a compile-time constant in the unrolled steady loop
@@ -216,7 +234,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         u32x4 frag[kFragRing];
         auto issue_reads = [&](auto ic) {   // LDS operand reads of MFMA ic
             constexpr int i = decltype(ic)::value;
-            if constexpr (kAblate == 1) {   // timing ablation: no LDS operand reads
+            if constexpr ((kAblate & 1) != 0) {   // timing ablation: no LDS operand reads
                 if constexpr (i < nAll) frag[i % kFragRing] = qf[i % G::kKSteps];
             } else if constexpr (i < nAll) {
                 if constexpr (i < nQ) {
@@ -239,9 +257,9 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         };
         auto issue_mfma = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (kAblate == 2) {   // timing ablation: no MFMA (operands kept alive)
+            if constexpr ((kAblate & 2) != 0) {   // timing ablation: no MFMA (operands kept alive)
                 keep_alive(frag[i % kFragRing]);
-            } else if constexpr (kAblate == 5) {   // timing ablation: reads issued, MFMA does not wait for them
+            } else if constexpr ((kAblate & 32) != 0) {   // timing ablation: reads issued, MFMA does not wait for them
                 if constexpr (i < nQ) {
                     constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
                     s_nxt[kb] = T::mfma32(qf[(ks + 1) % G::kKSteps], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
@@ -290,7 +308,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         };
         // The max chains read S(t+1) inside the slot sequence only when every QK^T MFMA has been
         // issued before the first of those steps (steady iterations); otherwise after the slots.
-        constexpr bool kMaxInSlots = kHasNext && kHasPrev && ((kSteps - 6) * nAll / kSteps >= nQ);
+        constexpr bool kMaxInSlots = kTrack && kHasNext && kHasPrev && ((kSteps - 6) * nAll / kSteps >= nQ);
         auto max_step = [&](auto kc) {   // 6 scores of S(t+1), three independent chains
             constexpr int e0 = 6 * decltype(kc)::value;
             constexpr int a0 = e0 < 32 ? e0 : 31, a1 = e0 + 1 < 32 ? e0 + 1 : 31, a2 = e0 + 2 < 32 ? e0 + 2 : 31;
@@ -301,7 +319,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         };
         auto valu_step = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr (kAblate == 3) {   // timing ablation: no softmax VALU
+            if constexpr ((kAblate & 4) != 0) {   // timing ablation: no softmax VALU
                 pk_cur[j >> 2][j & 3] = __builtin_bit_cast(unsigned, s_cur[(2 * j) >> 4][(2 * j) & 15]);
                 return;
             }
@@ -322,19 +340,19 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             static_for<nAll>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (i == kStageSlot && kAblate != 4) {
+                if constexpr (i == kStageSlot && !(kAblate & 8)) {
                     // land the staged tiles mid-iteration: the loads were issued at the top, and the
                     // LDS writes are long complete when the iteration reaches its barrier
-                    write_k((unsigned)t & 1u);   // K(t+2) -> slot t&1 (held K(t), last read in iteration t-1)
-                    write_v((unsigned)t & 1u);   // V(t)   -> slot t&1 (held V(t-2), last read in iteration t-1)
+                    write_k(st_land, (unsigned)t & 1u);   // K(t+2) -> slot t&1 (held K(t), last read in iteration t-1)
+                    write_v(st_land, (unsigned)t & 1u);   // V(t)   -> slot t&1 (held V(t-2), last read in iteration t-1)
                 }
                 // The SIMD arbitrates between its two waves by age; raising the priority around the
                 // short MFMA + LDS-read issue lets the younger wave feed the long-latency units as
                 // soon as it gets there instead of queueing behind the older wave's VALU stream.
-                __builtin_amdgcn_s_setprio(1);
+                if constexpr (FA_IL_SETPRIO) __builtin_amdgcn_s_setprio(1);
                 issue_mfma(ic);
                 issue_reads(std::integral_constant<int, i + kReadAhead>{});
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (FA_IL_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 // VALU steps [i*kSteps/nAll, (i+1)*kSteps/nAll)
                 constexpr int j0 = i * kSteps / nAll, j1 = (i + 1) * kSteps / nAll;
                 static_for<j1 - j0>([&](auto dj) { valu_step(std::integral_constant<int, j0 + decltype(dj)::value>{}); });
@@ -342,7 +360,10 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        if constexpr (kHasNext) {
+        if constexpr (kHasNext && !kTrack) {
+            if (mask_next) mask_tail(t + 1, s_nxt);   // only ever true in a peeled iteration
+        }
+        if constexpr (kHasNext && kTrack) {
             if constexpr (!kMaxInSlots) static_for<6>([&](auto kc) { max_step(kc); });
             if (mask_next) {   // only ever true in a peeled iteration
                 mask_tail(t + 1, s_nxt);
@@ -355,99 +376,120 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             if (__any(tmax - m_ref > kThr)) rescale(tmax, pk_cur);
         }
         stamp(tm_c);
-        if constexpr (kAblate != 4 && nAll == 0) {
-            write_k((unsigned)t & 1u);
-            write_v((unsigned)t & 1u);
+        if constexpr (!(kAblate & 8) && nAll == 0) {
+            write_k(st_land, (unsigned)t & 1u);
+            write_v(st_land, (unsigned)t & 1u);
         }
         if constexpr (kDiag) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stamp(tm_w);
-        if constexpr (kAblate != 6) __syncthreads();
+        if constexpr (!(kAblate & 16)) __syncthreads();
         stamp(tm_b);
     };
 
-    // ---- prologue: K(0), K(1) into LDS; S(0) and the exact row max of tile 0 ---------------------
+    // Two passes at most.  The optimistic pass fixes the reference max after tile 0 (row max of
+    // tile 0 plus kHeadroom) and never looks at a row max again: the 18 v_max3 + compare + branch
+    // per tile are pure cost on a vector-issue-bound loop (-4.6 % measured).  It is exact unless a
+    // later score exceeds the reference by more than the 16-bit format can hold (p = 2^(x-m) > 65504
+    // for fp16, > 3e38 for bf16): then p becomes inf, the row sum -- accumulated by MFMA from the very
+    // same packed P -- becomes inf/NaN, and that is tested once per row at the end.  If any row of the
+    // workgroup overflowed, the whole workgroup (staging is cooperative) re-runs in the tracking mode
+    // with the lazy running max.  Underflow is harmless: the reference is an actual score of the row,
+    // so one term has weight 2^-kHeadroom and anything that underflows is < 2^-24 of it.
+    constexpr float kHeadroom = 4.0f;
     f32x16 sA[2], sB[2];
     u32x4 pkA[4], pkB[4];
-    load_k(0);
-    write_k(0);
-    load_k(1);
-    write_k(1);
-    __syncthreads();
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < G::kKSteps; ++ks) {
-            const u32x4 kf = lds_read16(smem, kb * 32u * G::kRowBytes + k_rd_row + (((2u * ks + h) ^ k_rd_swz) << 4));
-            sA[kb] = T::mfma32(kf, qf[ks], ks == 0 ? zero16 : sA[kb]);
-        }
-    if (ntiles == 1 && partial) mask_tail(0, sA);
-    {
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) tmax = fmaxf(tmax, sA[e >> 4][e & 15]);
-        tmax *= c;
-        m_ref = fmaxf(tmax, swap_halves(tmax));
-    }
-    __syncthreads();   // all waves are done reading K(0) before iteration 0 overwrites its slot
-
     const std::true_type yes{};
     const std::false_type no{};
     const std::integral_constant<int, -1> rt{};   // ring-slot parity known only at run time
-    {
-        unsigned long long dummy = 0;
-        stamp(dummy);
-    }
-    if (ntiles == 1) {
-        iter(no, no, rt, 0, false, sA, sB, pkB, pkA);
-    } else {
-        iter(no, yes, rt, 0, partial && ntiles == 2, sA, sB, pkB, pkA);   // now: S in sB, P(0) in pkA
-        // steady iterations t in [1, t_end): the next tile is full, no masking
-        const int t_end = partial ? ntiles - 2 : ntiles - 1;
-        int t = 1;
-        for (; t + 1 < t_end; t += 2) {
-            iter(yes, yes, std::integral_constant<int, 0>{}, t, false, sB, sA, pkA, pkB);       // t odd
-            iter(yes, yes, std::integral_constant<int, 1>{}, t + 1, false, sA, sB, pkB, pkA);   // t+1 even
+    auto run = [&](auto track_c) {
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db) o[db] = zero16;
+        o_l = zero16;
+        // ---- prologue: K(0), K(1) into LDS; S(0) and the exact row max of tile 0 ---------------------
+        load_k(stA, 0);
+        load_k(stB, 1);
+        write_k(stA, 0);
+        write_k(stB, 1);
+        load_k(stA, 2);   // what iteration 0 lands
+        load_v(stA, 0);
+        __syncthreads();
+    #pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+    #pragma unroll
+            for (int ks = 0; ks < G::kKSteps; ++ks) {
+                const u32x4 kf = lds_read16(smem, kb * 32u * G::kRowBytes + k_rd_row + (((2u * ks + h) ^ k_rd_swz) << 4));
+                sA[kb] = T::mfma32(kf, qf[ks], ks == 0 ? zero16 : sA[kb]);
+            }
+        if (ntiles == 1 && partial) mask_tail(0, sA);
+        {
+            float tmax = -INFINITY;
+    #pragma unroll
+            for (int e = 0; e < 32; ++e) tmax = fmaxf(tmax, sA[e >> 4][e & 15]);
+            tmax *= c;
+            m_ref = fmaxf(tmax, swap_halves(tmax));
+            if constexpr (!decltype(track_c)::value) m_ref += kHeadroom;
         }
-        // leftovers in canonical naming (scores in sB, previous P in pkA), copying back each time
-        for (; t + 1 < ntiles; ++t) {
-            iter(yes, yes, rt, t, partial && (t + 2 == ntiles), sB, sA, pkA, pkB);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sB[kb] = sA[kb];
-#pragma unroll
+        __syncthreads();   // all waves are done reading K(0) before iteration 0 overwrites its slot
+
+        {
+            unsigned long long dummy = 0;
+            stamp(dummy);
+            tm_loop0 = tm_last;
+        }
+        if (ntiles == 1) {
+            iter(track_c, no, no, rt, 0, false, sA, sB, pkB, pkA, stA, stB);
+        } else {
+            iter(track_c, no, yes, rt, 0, partial && ntiles == 2, sA, sB, pkB, pkA, stA, stB);   // now: S in sB, P(0) in pkA
+            // steady iterations t in [1, t_end): the next tile is full, no masking
+            const int t_end = partial ? ntiles - 2 : ntiles - 1;
+            int t = 1;
+            for (; t + 1 < t_end; t += 2) {
+                iter(track_c, yes, yes, std::integral_constant<int, 0>{}, t, false, sB, sA, pkA, pkB, stB, stA);       // t odd
+                iter(track_c, yes, yes, std::integral_constant<int, 1>{}, t + 1, false, sA, sB, pkB, pkA, stA, stB);   // t+1 even
+            }
+            // leftovers in canonical naming (scores in sB, previous P in pkA), copying back each time
+            for (; t + 1 < ntiles; ++t) {
+                iter(track_c, yes, yes, rt, t, partial && (t + 2 == ntiles), sB, sA, pkA, pkB, stB, stA);
+    #pragma unroll
+                for (int kb = 0; kb < 2; ++kb) sB[kb] = sA[kb];
+    #pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
+                stB = stA;
+            }
+            iter(track_c, yes, no, rt, ntiles - 1, false, sB, sA, pkA, pkB, stB, stA);   // last tile: P in pkB
+    #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
         }
-        iter(yes, no, rt, ntiles - 1, false, sB, sA, pkA, pkB);   // last tile: P in pkB
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) pkA[k4] = pkB[k4];
-    }
-    if constexpr (kDiag) {
-        if (lane == 0 && diag) {
-            unsigned long long* dd = diag + ((size_t)bid * W + wave) * 4;
-            dd[0] = tm_c;
-            dd[1] = tm_w;
-            dd[2] = tm_b;
-            dd[3] = (unsigned long long)ntiles;
-        }
-    }
-    // ---- drain: O^T += V(last)^T.P(last)^T  (P in pkA; V(last) landed at the end of the last iteration)
-    {
-        const unsigned vbuf = (unsigned)(ntiles - 1) & 1u;
-#pragma unroll
-        for (int db = 0; db < G::kDBlocks; ++db)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                u32x4 vf;
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const u32x2 half = lds_read_tr8(
-                        smem, vbuf * G::kTileBytes + v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
-                    vf[2 * jj] = half[0];
-                    vf[2 * jj + 1] = half[1];
+        if constexpr (kDiag) tm_loop1 = tm_last;
+        // ---- drain: O^T += V(last)^T.P(last)^T  (P in pkA; V(last) landed at the end of the last iteration)
+        {
+            const unsigned vbuf = (unsigned)(ntiles - 1) & 1u;
+    #pragma unroll
+            for (int db = 0; db < G::kDBlocks; ++db)
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    u32x4 vf;
+    #pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const u32x2 half = lds_read_tr8(
+                            smem, vbuf * G::kTileBytes + v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
+                        vf[2 * jj] = half[0];
+                        vf[2 * jj + 1] = half[1];
+                    }
+                    o[db] = T::mfma32(vf, pkA[ks], o[db]);
                 }
-                o[db] = T::mfma32(vf, pkA[ks], o[db]);
-            }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) o_l = T::mfma32(ones, pkA[ks], o_l);
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks) o_l = T::mfma32(ones, pkA[ks], o_l);
+        }
+
+    };
+    run(no);
+    {
+        const bool bad = !(__builtin_fabsf(o_l[0]) < INFINITY);   // inf or NaN row sum
+        if (__syncthreads_or(bad ? 1 : 0)) {
+            __syncthreads();   // everybody is out of the first pass's LDS reads
+            run(yes);
+        }
     }
 
     // ---- normalise and store: lane holds O[q_row][db*32 + 8g + 4h + 0..3] in o[db][4g..4g+3] ---
@@ -469,6 +511,21 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                 const u32x2 v = {T::pack2(a, b), T::pack2(cc, d)};
                 buf_store8(ro, (q_row * D + col) * 2u, v);
             }
+        }
+    }
+    if constexpr (kDiag) {
+        unsigned long long tm_exit;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm_exit)::"memory");
+        if (lane == 0 && diag) {
+            unsigned long long* dd = diag + ((size_t)bid * W + wave) * 8;
+            dd[0] = tm_c;
+            dd[1] = tm_w;
+            dd[2] = tm_b;
+            dd[3] = (unsigned long long)ntiles;
+            dd[4] = tm_loop0 - tm_entry;   // prologue
+            dd[5] = tm_loop1 - tm_loop0;   // main loop
+            dd[6] = tm_exit - tm_loop1;    // drain + normalise + store (stores retired)
+            dd[7] = tm_entry;
         }
     }
 }
@@ -497,6 +554,35 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
                             int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream)
 {
     using G = TileGeom<64>;
+    if (waves >= 100) {   // the same ablations WITHOUT the in-kernel stamps (time them with events)
+        const int nqb = (N + 255) / 256;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
+                               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+        };
+        switch (waves - 100) {
+            case 0: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 0>); break;
+            case 1: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 1>); break;
+            case 2: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 2>); break;
+            case 4: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 4>); break;
+            case 5: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 5>); break;
+            case 6: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 6>); break;
+            case 7: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 7>); break;
+            case 8: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 8>); break;
+            case 15: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 15>); break;
+            case 11: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 11>); break;
+            case 13: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 13>); break;
+            case 14: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 14>); break;
+            case 9: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 9>); break;
+            case 10: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 10>); break;
+            case 12: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 12>); break;
+            case 31: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 31>); break;
+            case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 3>); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (waves >= 10) {   // 8-wave workgroups with one piece of the iteration removed (timing only, wrong results)
         const int nqb = (N + 255) / 256;
         auto go = [&](auto kern) {
@@ -504,13 +590,17 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                                static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
         };
-        switch (waves - 10) {
+        switch (waves - 10) {   // bit mask: 1 no LDS operand reads, 2 no MFMA, 4 no softmax VALU, 8 no staging, 16 no barrier
             case 1: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 1>); break;
             case 2: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 2>); break;
-            case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 3>); break;
             case 4: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 4>); break;
             case 5: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 5>); break;
             case 6: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 6>); break;
+            case 7: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 7>); break;
+            case 8: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 8>); break;
+            case 15: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 15>); break;
+            case 31: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 31>); break;
+            case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 3>); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

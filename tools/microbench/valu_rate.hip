@@ -115,6 +115,18 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
             REP16(X)
 #undef X
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (KIND == 23 || KIND == 24) {
+            // the MFMA + 8 VALU slot again, accumulator in the AGPR half of the file (23) and, for
+            // reference, VALU operands spread over many VGPRs as in the real kernel (24, VGPR accumulator)
+#define X(i) \
+            if (KIND == 23) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc16) : "v"(af), "v"(bf)); \
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accs[(i) & 3]) : "v"(af), "v"(bf)); \
+            asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_fma_f32 %1, %1, %3, %4\n\tv_exp_f32 %5, %5\n\tv_exp_f32 %6, %6\n\t" \
+                         "v_cvt_pk_f16_f32 %2, %7, %8\n\tv_add_f32 %9, %9, %7\n\tv_add_f32 %10, %10, %8\n\tv_max3_f32 %11, %11, %0, %1" \
+                         : "+v"(x[(i) & 3]), "+v"(x[4 + ((i) & 3)]), "=v"(y[(i) & 7]) : "v"(a), "v"(b), \
+                           "v"(x[8 + ((i) & 1)]), "v"(x[10 + ((i) & 1)]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]), "v"(x[12 + ((i) & 3)]));
+            REP16(X)
+#undef X
         } else if constexpr (KIND == 21) {   // MFMA, 4 independent accumulators
 #define X(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accs[(i) & 3]) : "v"(af), "v"(bf));
             REP16(X)
@@ -193,6 +205,8 @@ int main()
     run<16>("slot: 1 MFMA only              (per slot)", 16);
     run<21>("MFMA 32x32x16 f16, 4 independent accumulators", 16);
     run<22>("MFMA 16x16x32 f16, 4 independent accumulators", 16);
+    run<23>("slot: MFMA (AGPR acc) + 8 VALU", 16);
+    run<24>("slot: MFMA (4 VGPR accs) + 8 VALU", 16);
     run<17>("slot: MFMA + 2 ds_read_tr_b64 + 8 VALU", 16);
     run<18>("slot: MFMA + 1 ds_read_b128 + 8 VALU", 16);
     run<19>("slot: 2 ds_read_tr_b64 only", 16);
