@@ -31,6 +31,7 @@
 // flashattn_forward_wmma_v5_cp_async.cu:221-256).
 #include "fa_tile.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -53,6 +54,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 #ifndef FA_IL_NO_MAX
 #define FA_IL_NO_MAX 0   // experiment: skip the per-tile row max (UNSAFE: no overflow protection)
+#endif
+#ifndef FA_IL_SLOT_FENCE
+#define FA_IL_SLOT_FENCE 1
+#endif
+#ifndef FA_IL_STAGE_NUM
+#define FA_IL_STAGE_NUM 3
+#endif
+#ifndef FA_IL_FRONT_STEPS
+#define FA_IL_FRONT_STEPS 0   // VALU pair-steps issued right after the barrier, under the first LDS reads' latency
 #endif
 #ifndef FA_IL_MFMA_ORDER
 #define FA_IL_MFMA_ORDER 0
@@ -220,8 +230,10 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         constexpr bool kHasPrev = decltype(has_prev_c)::value;
         constexpr bool kHasNext = decltype(has_next_c)::value;
         constexpr int nQ = kHasNext ? nQK : 0, nP = kHasPrev ? nPV : 0, nAll = nQ + nP;
+        // slot -> MFMA index: QK^T first (order 0) or PV first (order 1); indices < nQ are QK^T MFMAs
+        auto mfma_of = [](int slot) constexpr { return FA_IL_MFMA_ORDER == 1 ? (slot < nP ? nQ + slot : slot - nP) : slot; };
         constexpr int kSteps = 16;   // VALU pair-steps (2 scores each)
-        constexpr int kStageSlot = nAll > 0 ? (3 * nAll) / 4 : -1;   // slot in front of which the staged tiles are written
+        constexpr int kStageSlot = nAll > 0 ? (FA_IL_STAGE_NUM * nAll) / 4 : -1;   // slot in front of which the staged tiles are written
 
         if constexpr (!(kAblate & 8)) {
             load_k(st_fetch, t + 3);   // requested now, landed in LDS during iteration t+1
@@ -232,14 +244,15 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         constexpr int kPar = decltype(par_c)::value;
         const unsigned kbuf = kPar >= 0 ? (unsigned)kPar : ((unsigned)(t + 1) & 1u), vbuf = kbuf;
         u32x4 frag[kFragRing];
-        auto issue_reads = [&](auto ic) {   // LDS operand reads of MFMA ic
-            constexpr int i = decltype(ic)::value;
+        auto issue_reads = [&](auto slot_c) {   // LDS operand reads of the MFMA in slot `slot`
+            constexpr int slot = decltype(slot_c)::value;
+            constexpr int i = slot < nAll ? mfma_of(slot) : nAll;
             if constexpr ((kAblate & 1) != 0) {   // timing ablation: no LDS operand reads
-                if constexpr (i < nAll) frag[i % kFragRing] = qf[i % G::kKSteps];
+                if constexpr (i < nAll) frag[slot % kFragRing] = qf[i % G::kKSteps];
             } else if constexpr (i < nAll) {
                 if constexpr (i < nQ) {
                     constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
-                    frag[i % kFragRing] = lds_read16(smem, kbuf * G::kTileBytes + kb * 32u * G::kRowBytes + k_rd_row +
+                    frag[slot % kFragRing] = lds_read16(smem, kbuf * G::kTileBytes + kb * 32u * G::kRowBytes + k_rd_row +
                                                                (((2u * ks + h) ^ k_rd_swz) << 4));
                 } else if constexpr ((i - nQ) / 4 < G::kDBlocks) {
                     constexpr int j = i - nQ, db = j / 4, ks = j % 4;
@@ -251,14 +264,15 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                         vf[2 * jj] = half[0];
                         vf[2 * jj + 1] = half[1];
                     }
-                    frag[i % kFragRing] = vf;
+                    frag[slot % kFragRing] = vf;
                 }
             }
         };
-        auto issue_mfma = [&](auto ic) {
-            constexpr int i = decltype(ic)::value;
+        auto issue_mfma = [&](auto slot_c) {
+            constexpr int slot = decltype(slot_c)::value;
+            constexpr int i = mfma_of(slot);
             if constexpr ((kAblate & 2) != 0) {   // timing ablation: no MFMA (operands kept alive)
-                keep_alive(frag[i % kFragRing]);
+                keep_alive(frag[slot % kFragRing]);
             } else if constexpr ((kAblate & 32) != 0) {   // timing ablation: reads issued, MFMA does not wait for them
                 if constexpr (i < nQ) {
                     constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
@@ -275,10 +289,10 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                 }
             } else if constexpr (i < nQ) {
                 constexpr int kb = i / G::kKSteps, ks = i % G::kKSteps;
-                s_nxt[kb] = T::mfma32(frag[i % kFragRing], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
+                s_nxt[kb] = T::mfma32(frag[slot % kFragRing], qf[ks], ks == 0 ? zero16 : s_nxt[kb]);
             } else if constexpr ((i - nQ) / 4 < G::kDBlocks) {
                 constexpr int j = i - nQ, db = j / 4, ks = j % 4;
-                o[db] = T::mfma32(frag[i % kFragRing], pk_prev[ks], o[db]);
+                o[db] = T::mfma32(frag[slot % kFragRing], pk_prev[ks], o[db]);
             } else {
                 o_l = T::mfma32(ones, pk_prev[(i - nQ) % 4], o_l);   // row sums: no LDS operand
             }
@@ -308,7 +322,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         };
         // The max chains read S(t+1) inside the slot sequence only when every QK^T MFMA has been
         // issued before the first of those steps (steady iterations); otherwise after the slots.
-        constexpr bool kMaxInSlots = kTrack && kHasNext && kHasPrev && ((kSteps - 6) * nAll / kSteps >= nQ);
+        constexpr bool kMaxInSlots = kTrack && FA_IL_MFMA_ORDER == 0 && kHasNext && kHasPrev && ((kSteps - 6) * nAll / kSteps >= nQ);
         auto max_step = [&](auto kc) {   // 6 scores of S(t+1), three independent chains
             constexpr int e0 = 6 * decltype(kc)::value;
             constexpr int a0 = e0 < 32 ? e0 : 31, a1 = e0 + 1 < 32 ? e0 + 1 : 31, a2 = e0 + 2 < 32 ? e0 + 2 : 31;
@@ -334,12 +348,19 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         fma_pair(std::integral_constant<int, 0>{});
         fma_pair(std::integral_constant<int, 1>{});
         exp_pair(std::integral_constant<int, 0>{});
+        constexpr int kFront = (nAll > 0 && !kMaxInSlots) ? FA_IL_FRONT_STEPS : 0;
+        if constexpr (kFront > 0) {
+            // Every LDS read of this iteration is of data that became visible at the barrier just
+            // passed, so the first MFMA cannot issue for one LDS round trip: fill it with VALU work.
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<kFront>([&](auto jc) { valu_step(jc); });
+        }
         if constexpr (nAll == 0) {
             static_for<kSteps>([&](auto jc) { valu_step(jc); });
         } else {
             static_for<nAll>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FA_IL_SLOT_FENCE) __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i == kStageSlot && !(kAblate & 8)) {
                     // land the staged tiles mid-iteration: the loads were issued at the top, and the
                     // LDS writes are long complete when the iteration reaches its barrier
@@ -354,7 +375,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                 issue_reads(std::integral_constant<int, i + kReadAhead>{});
                 if constexpr (FA_IL_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 // VALU steps [i*kSteps/nAll, (i+1)*kSteps/nAll)
-                constexpr int j0 = i * kSteps / nAll, j1 = (i + 1) * kSteps / nAll;
+                constexpr int j0 = kFront + i * (kSteps - kFront) / nAll, j1 = kFront + (i + 1) * (kSteps - kFront) / nAll;
                 static_for<j1 - j0>([&](auto dj) { valu_step(std::integral_constant<int, j0 + decltype(dj)::value>{}); });
             });
         }
@@ -536,13 +557,16 @@ static hipError_t launch_il(const void* Q, const void* K, const void* V, void* O
 {
     using G = TileGeom<D>;
     auto kern = fa_fwd_il_kernel<T, D, kOutF32, W>;
+    // FA_IL_LDS_BYTES (experiments only): request more LDS than needed to lower the occupancy
+    static const int lds_req = [] { const char* v = getenv("FA_IL_LDS_BYTES"); return v ? atoi(v) : 0; }();
+    const int lds_bytes = lds_req > G::kLdsBytes ? lds_req : G::kLdsBytes;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
     const int nqb = (N + 32 * W - 1) / (32 * W);
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * W), G::kLdsBytes, stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * W), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e,
                        static_cast<unsigned long long*>(nullptr));
@@ -554,6 +578,32 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
                             int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream)
 {
     using G = TileGeom<64>;
+    if (waves >= 200) {   // ablations of the 4-wave kernel at ONE workgroup per CU (one wave per SIMD), no stamps
+        const int nqb = (N + 127) / 128;
+        const int lds = 96 * 1024;   // more than half of the CU's LDS: occupancy 1
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(256), lds, stream,
+                               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+        };
+        switch (waves - 200) {
+            case 0: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 0>); break;
+            case 1: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 1>); break;
+            case 2: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 2>); break;
+            case 4: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 4>); break;
+            case 8: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 8>); break;
+            case 9: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 9>); break;
+            case 11: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 11>); break;
+            case 13: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 13>); break;
+            case 14: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 14>); break;
+            case 12: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 12>); break;
+            case 10: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 10>); break;
+            case 31: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 31>); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (waves >= 100) {   // the same ablations WITHOUT the in-kernel stamps (time them with events)
         const int nqb = (N + 255) / 256;
         auto go = [&](auto kern) {

@@ -27,13 +27,15 @@ extern "C" {
 #define FA_OUT_F32    0   /* the reference's output type */
 #define FA_OUT_SAME   1   /* output in the input's 16-bit type */
 
-#define FA_ALGO_AUTO    0
-#define FA_ALGO_GENERIC 1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
-#define FA_ALGO_TILED   2 /* LDS-staged 256-row workgroups, D in {64,128} */
-#define FA_ALGO_PIPE    3 /* the same, software-pipelined (QK^T of tile t+1 under softmax of tile t), D = 64 */
-#define FA_ALGO_INTERLEAVED 5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
-#define FA_ALGO_INTERLEAVED_2WG 6 /* the same with 128-row workgroups, two per CU */
-#define FA_ALGO_PINGPONG 4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
+#define FA_ALGO_AUTO            0 /* d=64: INTERLEAVED (or _2WG when the grid is small); d=128: TILED; else GENERIC */
+#define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
+#define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
+#define FA_ALGO_PIPE            3 /* the same with QK^T of tile t+1 under the softmax of tile t, D = 64 */
+#define FA_ALGO_PINGPONG        4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
+#define FA_ALGO_INTERLEAVED     5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
+#define FA_ALGO_INTERLEAVED_2WG 6 /* the same with 128-row workgroups, two per CU, D = 64 */
+#define FA_ALGO_TLP3            9 /* simple per-wave stream, three 128-row workgroups per CU, D = 64 */
+/* 7, 8, 10: experimental occupancy variants kept for A/B timing (fp16, d=64). */
 
 /* General-shape forward.  Replaces
  *   flashattn_forward_wmma_kernel(const half* Q, const half* K, const half* V, float* O,

@@ -41,7 +41,7 @@ def _run(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False, scale=None):
 
 
 def _algos_for(d):
-    return (0, 1, 2, 3, 4, 5, 6) if d == 64 else ((0, 1, 2, 4) if d == 128 else (0, 1))
+    return (0, 1, 2, 3, 4, 5, 6, 9, 10) if d == 64 else ((0, 1, 2, 4) if d == 128 else (0, 1))
 
 
 def _check(oracle, got, want, fmt, what, out_same=False):
@@ -259,3 +259,41 @@ def test_device_rejects_bad_shapes(fa, torch_cuda):
     q = torch.zeros(1, 128, 32, dtype=torch.float16, device="cuda")
     with pytest.raises(fa.FaError):
         fa.fa_forward(q, q, q, algo=2)               # tiled kernel needs D in {64,128}
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
+    """The d=64 kernels first run without tracking the row max (reference = max of tile 0 + 2^4) and
+    re-run a workgroup in tracking mode when a row sum comes out inf/NaN.  Force exactly that, in
+    the corner cases: overflow in the very last tile only, for a single query row only, just above
+    and just below the 16-bit overflow point, and a whole block whose first tile is far below the rest."""
+    n, d, bh = 640, 64, 3
+    (q, k, v), _ = oracle.make_qkv(bh, n, d, fmt, seed=777 + fmt)
+    ln2 = float(np.log(2.0))
+
+    def spike(b, qi, key, log2_above):
+        # make score(qi,key)*log2e exceed that row's tile-0 max by ~log2_above
+        s0 = (q[b, qi] @ k[b, :64].T) / np.sqrt(d)
+        target = (s0.max() + log2_above * ln2) * np.sqrt(d)
+        k[b, key] = q[b, qi] * (target / float(q[b, qi] @ q[b, qi]))
+
+    spike(0, 5, n - 1, 40.0)        # one row, last key of the last tile, far beyond fp16 range
+    spike(0, 300, 100, 19.0)        # below the overflow point (4 + 16 = 20): stays in the optimistic pass if alone
+    spike(1, 77, 333, 21.5)         # just above it
+    spike(1, 78, 334, 150.0 if fmt == 1 else 60.0)   # bf16 overflows only past 2^128
+    k[2, 64:] *= 6.0                # rows of head 2: everything after tile 0 is much larger
+    q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
+    qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
+    want = oracle.forward(q, k, v, accum=1, nthreads=8)
+    for algo in (0, 5, 6, 9):
+        got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
+        _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}")
+    # ragged N with the overflow in the partial last tile
+    n2 = 333
+    (q2, k2, v2), _ = oracle.make_qkv(1, n2, d, fmt, seed=9)
+    k2[0, n2 - 1] = q2[0, 200] * 40.0
+    q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
+    want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
+    for algo in (0, 5, 6, 9):
+        got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
+        _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}")

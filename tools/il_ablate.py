@@ -31,6 +31,12 @@ def run(m, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
+BASE = int(sys.argv[1]) if len(sys.argv) > 1 else 100   # 100: 8 waves, 2 per SIMD; 200: 4 waves, ONE per SIMD
+if BASE == 200:
+    modes = [0, 8, 11, 13, 14, 9, 10, 12, 31]
+tiles_per_simd = 512 if BASE == 100 else 1024             # wave-tile slots a SIMD runs back to back
+_run = run
+run = lambda m, iters=10: _run(m - 100 + BASE, iters)
 for m in modes:
     run(m, 3)
 res = {m: [] for m in modes}
@@ -39,4 +45,4 @@ for _ in range(5):
         res[m].append(run(m))
 for m in modes:
     t = statistics.median(res[m])
-    print(f"{names[m]:28s} {t:.4f} ms   ~{t * 1e-3 * 2.0e9 / 512:.0f} cycles per tile per CU at 2.0 GHz")
+    print(f"{names[m]:28s} {t:.4f} ms   ~{t * 1e-3 * 2.0e9 / tiles_per_simd:.0f} cycles per {'tile-pair' if BASE == 100 else 'wave-tile'} per SIMD at 2.0 GHz")
