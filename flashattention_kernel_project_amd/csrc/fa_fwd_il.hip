@@ -82,7 +82,8 @@ template <typename T, int D, bool kOutF32, int W, bool kDiag = false, int kAblat
 __global__ __launch_bounds__(64 * W, 2)
 void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                       const uint16_t* __restrict__ Vg, void* __restrict__ Og,
-                      int N, int nqb, float scale_log2e, unsigned long long* __restrict__ diag = nullptr)
+                      int N, int nqb, float scale_log2e, unsigned long long* __restrict__ diag = nullptr,
+                      unsigned total_wg = 0)
 {
     unsigned long long tm_c = 0, tm_w = 0, tm_b = 0, tm_last = 0, tm_entry = 0, tm_loop0 = 0, tm_loop1 = 0;
     if constexpr (kDiag) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm_entry)::"memory");
@@ -101,8 +102,15 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
     constexpr int kRowsWG = 32 * W;                              // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0][K1][V0][V1]
 
-    // ---- block -> (head, query block): blocks that share K/V sit on one XCD, consecutively ----
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    // ---- persistent workgroups: the launch fills the chip once (grid = CUs x workgroups per CU) and
+    // each workgroup walks the work items bid, bid + grid, ...  This removes the per-workgroup
+    // dispatch gap (8 back-to-back workgroups per CU at B=8,H=16,N=4096 otherwise) and lets the
+    // output stores of one item drain under the next item's prologue.  Item order per CU is the
+    // order the dispatcher would have used, so the XCD affinity of a head's K/V is unchanged.
+    const unsigned nwg = total_wg ? total_wg : gridDim.x;
+    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    if (bid != blockIdx.x) __syncthreads();   // the previous item's last LDS reads are done
+    // ---- item -> (head, query block): items that share K/V sit on one XCD, consecutively ----
     const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
     const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const unsigned bh = wgid / (unsigned)nqb;
@@ -549,6 +557,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             dd[7] = tm_entry;
         }
     }
+    }   // persistent loop over work items
 }
 
 template <typename T, int D, bool kOutF32, int W>
@@ -566,10 +575,19 @@ static hipError_t launch_il(const void* Q, const void* K, const void* V, void* O
     const int nqb = (N + 32 * W - 1) / (32 * W);
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * W), lds_bytes, stream,
+    // persistent grid: one resident generation of workgroups (8 waves per CU at <= 256 VGPRs)
+    static const int grid_cap = [] {
+        const char* v = getenv("FA_IL_GRID");   // experiments: 0 = one workgroup per item
+        if (v) return atoi(v);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * (8 / W);
+    }();
+    const unsigned grid = (grid_cap > 0 && nwg > grid_cap) ? (unsigned)grid_cap : (unsigned)nwg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e,
-                       static_cast<unsigned long long*>(nullptr));
+                       static_cast<unsigned long long*>(nullptr), (unsigned)nwg);
     return hipGetLastError();
 }
 
@@ -585,7 +603,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(256), lds, stream,
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
-                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
         };
         switch (waves - 200) {
             case 0: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 0>); break;
@@ -609,7 +627,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
-                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
         };
         switch (waves - 100) {
             case 0: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 0>); break;
@@ -638,7 +656,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
-                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+                               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
         };
         switch (waves - 10) {   // bit mask: 1 no LDS operand reads, 2 no MFMA, 4 no softmax VALU, 8 no staging, 16 no barrier
             case 1: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 1>); break;
@@ -659,12 +677,12 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
         const int nqb = (N + 255) / 256;
         hipLaunchKernelGGL((fa_fwd_il_kernel<F16, 64, true, 8, true>), dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
                            static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
-                           static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+                           static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
     } else {
         const int nqb = (N + 127) / 128;
         hipLaunchKernelGGL((fa_fwd_il_kernel<F16, 64, true, 4, true>), dim3((unsigned)(BH * nqb)), dim3(256), G::kLdsBytes, stream,
                            static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
-                           static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag);
+                           static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
     }
     return hipGetLastError();
 }
