@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def one(pattern):
     fs = glob.glob(pattern, recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None   # newest (gpurun merges runs into one tree)
 
 
 def pmc_avgs(d, kernel_substr="fa_fwd"):
