@@ -50,9 +50,13 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    ranks = Ranks(backend="nccl" if world > 1 else None)
-    dev = torch.device("cuda", ranks.local_rank)
+    # FA_BENCH_BACKEND=gloo + FA_BENCH_ONE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box
+    # (all ranks on cuda:0, gloo carries the barrier / max reduction).  The driver's runs use RCCL.
+    backend = os.environ.get("FA_BENCH_BACKEND", "nccl") if world > 1 else None
+    local = 0 if os.environ.get("FA_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ranks = Ranks(backend=backend)
 
     B, H, N, d = args.B, args.H, args.N, args.d
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16

@@ -24,7 +24,7 @@ class Ranks:
                 kw = {}
                 if backend == "nccl":
                     import torch
-                    kw["device_id"] = torch.device("cuda", self.local_rank)
+                    kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
                 dist.init_process_group(backend=backend or "gloo", rank=self.rank, world_size=self.world, **kw)
                 self._pg = True
 
