@@ -64,6 +64,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef FA_IL_FRONT_STEPS
 #define FA_IL_FRONT_STEPS 0   // VALU pair-steps issued right after the barrier, under the first LDS reads' latency
 #endif
+#ifndef FA_IL_OCC
+#define FA_IL_OCC 2   // waves per SIMD the register budget is held to (experiments: 3 forces spills)
+#endif
 #ifndef FA_IL_MFMA_ORDER
 #define FA_IL_MFMA_ORDER 0
 #endif
@@ -79,7 +82,7 @@ constexpr int kFragRing  = kReadAhead + 1;
 // tile in ~1360 cycles, the younger in ~2180, and the older then idles at the workgroup barrier);
 // across workgroups nobody waits for the slower wave, so the unfairness costs nothing.
 template <typename T, int D, bool kOutF32, int W, bool kDiag = false, int kAblate = 0>
-__global__ __launch_bounds__(64 * W, 2)
+__global__ __launch_bounds__(64 * W, FA_IL_OCC)
 void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                       const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                       int N, int nqb, float scale_log2e, unsigned long long* __restrict__ diag = nullptr,

@@ -8,7 +8,7 @@
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int KIND>
-__global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters, float a, float b)
+__global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, int iters, float a, float b)
 {
     float x[16];
 #pragma unroll
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
     if ((threadIdx.x & 63) == 0) {
         cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
-        cyc[2048 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r1 - r0;
+        cyc[4096 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r1 - r0;
     }
 }
 
@@ -165,17 +165,17 @@ void run(const char* name, int per_iter)
     const int iters = 2000, nblk = 256;
     float* out;
     unsigned long long* cyc;
-    hipMalloc(&out, nblk * 512 * 4);
-    hipMalloc(&cyc, 4096 * 8);
-    for (int threads : {256, 512}) {
+    hipMalloc(&out, nblk * 1024 * 4);
+    hipMalloc(&cyc, 8192 * 8);
+    for (int threads : {256, 512, 768, 1024}) {
         hipLaunchKernelGGL(k<KIND>, dim3(nblk), dim3(threads), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
         hipLaunchKernelGGL(k<KIND>, dim3(nblk), dim3(threads), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
         hipDeviceSynchronize();
-        std::vector<unsigned long long> h(4096);
+        std::vector<unsigned long long> h(8192);
         hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
         const int nw = nblk * threads / 64;
         double s = 0, rt = 0;
-        for (int i = 0; i < nw; ++i) { s += (double)h[i]; rt += (double)h[2048 + i]; }
+        for (int i = 0; i < nw; ++i) { s += (double)h[i]; rt += (double)h[4096 + i]; }
         s /= nw; rt /= nw;
         printf("%-44s %d waves/SIMD: %6.2f ticks per instruction (per wave); memtime/memrealtime = %.2f -> %.0f MHz if realtime is 100 MHz\n",
                name, threads / 256, s / ((double)iters * per_iter), s / rt, s / rt * 100.0);
