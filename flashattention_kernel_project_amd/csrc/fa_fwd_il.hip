@@ -67,6 +67,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef FA_IL_OCC
 #define FA_IL_OCC 2   // waves per SIMD the register budget is held to (experiments: 3 forces spills)
 #endif
+#ifndef FA_IL_MFMA_SUM
+#define FA_IL_MFMA_SUM 0   // 0: row sums by v_add on the fp32 p (default: the kernel is POWER-limited and 4 extra MFMAs per tile cost more energy than 34 v_add; -4.9 % wall); 1: by 4 MFMAs against an all-ones fragment
+#endif
 #ifndef FA_IL_MFMA_ORDER
 #define FA_IL_MFMA_ORDER 0
 #endif
@@ -196,6 +199,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
     float m_ref = 0.0f;    // reference max of this lane's query row, log2 units (c*S)
+    float l_part = 0.0f;   // FA_IL_MFMA_SUM == 0: this half-wave's share of the row sum (fp32 p, v_add)
     f32x16 o_l = zero16;   // row sums: accumulator of ones(32x16).P^T, every register = l of this lane's row
     const u32x4 ones = {T::kOnes2, T::kOnes2, T::kOnes2, T::kOnes2};
 
@@ -203,7 +207,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
     const bool partial = (N % kBlockN) != 0;
 
     constexpr int nQK = 2 * G::kKSteps;   // MFMAs of S(t+1) = K.Q^T
-    constexpr int nPV = 4 * (G::kDBlocks + 1);  // MFMAs of O^T += V^T.P^T plus the row-sum block (A = ones)
+    constexpr int nPV = 4 * (G::kDBlocks + FA_IL_MFMA_SUM);  // MFMAs of O^T += V^T.P^T (plus the row-sum block, A = ones)
 
     auto keep_alive = [&](u32x4& v) { asm volatile("" : "+v"(v)); };
     auto mask_tail = [&](int tile, f32x16 (&s)[2]) {   // keys >= N -> -inf (p = 0)
@@ -226,6 +230,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
 #pragma unroll
         for (int i = 0; i < 16; ++i) o_l[i] *= alpha;
+        l_part *= alpha;
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4)   // P(t) is still waiting for its PV: bring it to the new scale too
 #pragma unroll
@@ -313,7 +318,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         //   step j:  fma of pair j+2, exp of pair j+1, pack + row-sum of pair j,
         //            and (last six steps) three max chains over S(t+1).
         const float neg_m = -m_ref;
-        float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
+        float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, ls0 = 0.0f, ls1 = 0.0f;
         const f32x2 c2 = {c, c}, neg_m2 = {neg_m, neg_m};
         auto fma_pair = [&](auto jc) {   // one v_pk_fma_f32 for the two scores of the pair
             constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;
@@ -330,6 +335,10 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         auto fin_pair = [&](auto jc) {
             constexpr int j = decltype(jc)::value, e0 = 2 * j, e1 = e0 + 1;
             pk_cur[j >> 2][j & 3] = T::pack2(s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]);
+            if constexpr (!FA_IL_MFMA_SUM) {
+                ls0 += s_cur[e0 >> 4][e0 & 15];
+                ls1 += s_cur[e1 >> 4][e1 & 15];
+            }
         };
         // The max chains read S(t+1) inside the slot sequence only when every QK^T MFMA has been
         // issued before the first of those steps (steady iterations); otherwise after the slots.
@@ -391,6 +400,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             });
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!FA_IL_MFMA_SUM) l_part += ls0 + ls1;
 
         if constexpr (kHasNext && !kTrack) {
             if (mask_next) mask_tail(t + 1, s_nxt);   // only ever true in a peeled iteration
@@ -437,6 +447,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 #pragma unroll
         for (int db = 0; db < G::kDBlocks; ++db) o[db] = zero16;
         o_l = zero16;
+        l_part = 0.0f;
         // ---- prologue: K(0), K(1) into LDS; S(0) and the exact row max of tile 0 ---------------------
         load_k(stA, 0);
         load_k(stB, 1);
@@ -511,13 +522,16 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
                     o[db] = T::mfma32(vf, pkA[ks], o[db]);
                 }
     #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) o_l = T::mfma32(ones, pkA[ks], o_l);
+            for (int ks = 0; ks < 4; ++ks)
+                if constexpr (FA_IL_MFMA_SUM) o_l = T::mfma32(ones, pkA[ks], o_l);
         }
 
     };
     run(no);
     {
-        const bool bad = !(__builtin_fabsf(o_l[0]) < INFINITY);   // inf or NaN row sum
+        // without the MFMA row sum: a packed p can only have overflowed if the fp32 row sum reached the format's range
+        const float l_chk = FA_IL_MFMA_SUM ? o_l[0] : l_part + swap_halves(l_part);
+        const bool bad = !(__builtin_fabsf(l_chk) < (FA_IL_MFMA_SUM || T::id == 1 ? INFINITY : 60000.0f));
         if (__syncthreads_or(bad ? 1 : 0)) {
             __syncthreads();   // everybody is out of the first pass's LDS reads
             run(yes);
@@ -525,7 +539,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
     }
 
     // ---- normalise and store: lane holds O[q_row][db*32 + 8g + 4h + 0..3] in o[db][4g..4g+3] ---
-    const float inv = 1.0f / o_l[0];   // every register of o_l holds the full row sum
+    const float inv = 1.0f / (FA_IL_MFMA_SUM ? o_l[0] : l_part + swap_halves(l_part));   // every register of o_l holds the full row sum
     constexpr unsigned es = kOutF32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t ro =
         make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));

@@ -127,6 +127,20 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, i
                            "v"(x[8 + ((i) & 1)]), "v"(x[10 + ((i) & 1)]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]), "v"(x[12 + ((i) & 3)]));
             REP16(X)
 #undef X
+        } else if constexpr (KIND == 25 || KIND == 26) {
+            // 16-row design: slot = one 16x16x32 MFMA + LDS operand reads + its share of the softmax VALU
+            // (per 16x64 wave-tile: 18 MFMA, 24 reads, 8 pk_fma + 16 exp + 8 cvt); 25: 2 tr reads per slot,
+            // 26: one b128 read per slot
+#define X(i) \
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[(i) & 3]) : "v"(af), "v"(bf)); \
+            if (KIND == 25) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" \
+                              : "=v"(ld2[(2 * (i)) & 7]), "=v"(ld2[(2 * (i) + 1) & 7]) : "v"(lds_addr), "i"(((i) & 7) * 1024), "i"(((i) & 7) * 1024 + 512)); \
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[(i) & 3]) : "v"(lds_addr), "i"(((i) & 7) * 1024)); \
+            if ((i) & 1) asm volatile("v_exp_f32 %0, %0\n\tv_cvt_pk_f16_f32 %1, %2, %3" : "+v"(x[(i) & 7]), "=v"(y[(i) & 7]) : "v"(x[8 + ((i) & 3)]), "v"(x[12 + ((i) & 3)])); \
+            else asm volatile("v_exp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %2, %2" : "+v"(x[(i) & 7]), "+v"(*(double*)&x[8 + 2 * ((i) & 3)]) : "v"(*(double*)&x[8 + 2 * ((i) & 3)]));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if constexpr (KIND == 21) {   // MFMA, 4 independent accumulators
 #define X(i) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accs[(i) & 3]) : "v"(af), "v"(bf));
             REP16(X)
@@ -207,6 +221,8 @@ int main()
     run<22>("MFMA 16x16x32 f16, 4 independent accumulators", 16);
     run<23>("slot: MFMA (AGPR acc) + 8 VALU", 16);
     run<24>("slot: MFMA (4 VGPR accs) + 8 VALU", 16);
+    run<25>("slot16: MFMA16x16x32 + 2 tr reads + 2 VALU", 16);
+    run<26>("slot16: MFMA16x16x32 + 1 b128 read + 2 VALU", 16);
     run<17>("slot: MFMA + 2 ds_read_tr_b64 + 8 VALU", 16);
     run<18>("slot: MFMA + 1 ds_read_b128 + 8 VALU", 16);
     run<19>("slot: 2 ds_read_tr_b64 only", 16);
