@@ -427,6 +427,13 @@ hipError_t il16_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream);
 
+hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
+                        int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                        hipStream_t stream);
+hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
+                           int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                           hipStream_t stream);
+
 // algo: 0 auto, 1 generic single-fragment kernel, 2 tiled kernel (D in {64,128} only),
 //       3 software-pipelined tiled kernel (D = 64 only), 4 ping-pong tiled kernel (D in {64,128})
 hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O,
@@ -451,6 +458,8 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
         return algo == 7 ? launch_tiled<F16, 64, true, 4, 3>(Q, K, V, O, BH, N, scale, stream)
                          : launch_tiled<F16, 64, true, 4, 2>(Q, K, V, O, BH, N, scale, stream);
     }
+    if (algo == 12) return il2x16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 11) return il16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);

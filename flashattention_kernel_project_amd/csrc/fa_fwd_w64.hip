@@ -1,0 +1,308 @@
+// fa_fwd_w64.hip -- attention forward with 64 query rows per wave, 512-row workgroups (gfx950, d = 64).
+//
+// The d=64 forward runs at the package power cap (1 380 W, sclk 1.85 GHz), so wall
+// time is set by joules per launch, not by cycles.  Sustained-load ablations of the 32-row kernel put
+// the energy at roughly 55 % matrix work, 25 % softmax VALU, 10 % LDS operand reads and 10 % K/V
+// staging (L2 -> VGPR -> LDS).  The last two are per-wave and per-workgroup overheads of the
+// DECOMPOSITION, not of the arithmetic: here every wave owns two 32-row query blocks, so each K and
+// V^T fragment read from LDS feeds two MFMAs, and a workgroup of 8 waves covers 512 query rows, so
+// each staged K/V tile serves twice the rows -- both overheads halve.  With a single score set per
+// wave there is no room (or need: the clock, not the issue stream, is the limit) for the software
+// pipeline of fa_fwd_il.hip; the per-tile stream is QK^T (16 MFMA) -> softmax -> PV (16 MFMA).
+//
+// Everything else is as in fa_fwd_il.hip: S^T = K.Q^T orientation, packed P straight from the
+// accumulator registers, optimistic pass without per-tile row max + tracked re-run on overflow,
+// fp32 row sums by v_add, packed fma, persistent grid, XCD-aware item order.
+#include "fa_tile.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace fa {
+
+namespace w64 {
+template <int... I, typename F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+constexpr int kW = 8;            // waves per workgroup
+constexpr int kRows = 64 * kW;   // 512 query rows per workgroup
+constexpr int kAhead = 2, kRing = kAhead + 1;   // LDS fragment read-ahead
+}  // namespace w64
+
+template <typename T, bool kOutF32>
+__global__ __launch_bounds__(64 * w64::kW, 2)
+void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                       const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                       int N, int nqb, float scale_log2e, unsigned total_wg)
+{
+    using namespace w64;
+    constexpr int D = 64;
+    using G = TileGeom<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][K tile][V tile]
+
+    const unsigned tid  = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane = tid & 63u;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const float c = fabsf(scale_log2e);
+    const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
+    const int ntiles = (N + kBlockN - 1) / kBlockN;
+    const bool partial = (N % kBlockN) != 0;
+
+    // staging: one 16-B chunk of K and one of V per thread and tile
+    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
+    const unsigned st_goff = srow * G::kRowBytes + sch * 16u;
+    const unsigned k_lds = G::k_off(srow, sch);
+    const unsigned v_lds = G::kTileBytes + G::v_off(srow, sch);
+
+    const unsigned k_rd_row = r * G::kRowBytes;
+    const unsigned k_rd_swz = G::k_swz(r);
+    const unsigned i16 = lane & 15u, vq = i16 >> 2, vp = i16 & 3u, vg = (lane >> 4) & 1u;
+    unsigned v_rd[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        v_rd[par] = G::kTileBytes + h * G::kDBlocks * 256u + ((vq ^ par) << 6) + vg * 32u + vp * 8u;
+
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
+    constexpr float kHeadroom = 4.0f;
+    const std::true_type yes{};
+    const std::false_type no{};
+
+    const unsigned nwg = total_wg;
+    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    if (bid != blockIdx.x) __syncthreads();
+    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const unsigned bh = wgid / (unsigned)nqb;
+    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+    const unsigned q_row0 = qb * kRows + wave * 64u + r;   // row of query block 0; block 1 is 32 rows further
+
+    u32x4 qf[2][G::kKSteps];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s = 0; s < G::kKSteps; ++s) {
+            u32x4 raw = buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) raw[w] ^= q_flip;
+            qf[x][s] = raw;
+        }
+
+    f32x16 o[2][G::kDBlocks];
+    float m_ref[2] = {0.0f, 0.0f}, l_part[2] = {0.0f, 0.0f};
+    u32x4 kst, vst;
+
+    auto run = [&](auto track_c) __attribute__((always_inline)) {
+        constexpr bool kTrack = decltype(track_c)::value;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
+            l_part[x] = 0.0f;
+        }
+        kst = buf_load16(rk, st_goff);
+        vst = buf_load16(rv, st_goff);
+        lds_write16(smem, k_lds, kst);
+        lds_write16(smem, v_lds, vst);
+        __syncthreads();
+
+        for (int t = 0; t < ntiles; ++t) {
+            const unsigned cur = (unsigned)t & 1u;
+            // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
+            kst = buf_load16(rk, (unsigned)(t + 1) * G::kTileBytes + st_goff);
+            vst = buf_load16(rv, (unsigned)(t + 1) * G::kTileBytes + st_goff);
+
+            // ---- S^T = K.Q^T for both query blocks: each K fragment feeds two MFMAs ------------
+            f32x16 s[2][2];
+            u32x4 frag[kRing];
+            auto read_k = [&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr (f < 2 * G::kKSteps) {
+                    constexpr int kb = f / G::kKSteps, ks = f % G::kKSteps;
+                    frag[f % kRing] = lds_read16(smem, cur * G::kBufBytes + kb * 32u * G::kRowBytes + k_rd_row +
+                                                           (((2u * ks + h) ^ k_rd_swz) << 4));
+                }
+            };
+            sfor<kAhead>([&](auto fc) { read_k(fc); });
+            sfor<2 * G::kKSteps>([&](auto fc) {
+                constexpr int f = decltype(fc)::value, kb = f / G::kKSteps, ks = f % G::kKSteps;
+                s[0][kb] = T::mfma32(frag[f % kRing], qf[0][ks], ks == 0 ? zero16 : s[0][kb]);
+                s[1][kb] = T::mfma32(frag[f % kRing], qf[1][ks], ks == 0 ? zero16 : s[1][kb]);
+                read_k(std::integral_constant<int, f + kAhead>{});
+            });
+
+            if (partial && t + 1 == ntiles) {   // keys >= N -> -inf (p = 0)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                            if (key >= N) s[x][kb][i] = -INFINITY;
+                        }
+            }
+
+            // ---- reference max: tile 0 always; later tiles only in the tracked (fallback) pass ----
+            if (kTrack || t == 0) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    float tmax = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 32; e += 2) tmax = max3(tmax, s[x][e >> 4][e & 15], s[x][(e + 1) >> 4][(e + 1) & 15]);
+                    tmax *= c;
+                    if (t == 0) {
+                        m_ref[x] = fmaxf(tmax, swap_halves(tmax)) + (kTrack ? 0.0f : kHeadroom);
+                    } else if (__any(tmax - m_ref[x] > kThr)) {
+                        const float m_new = fmaxf(fmaxf(tmax, swap_halves(tmax)), m_ref[x]);
+                        const float alpha = fast_exp2(m_ref[x] - m_new);
+                        m_ref[x] = m_new;
+#pragma unroll
+                        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) o[x][db][i] *= alpha;
+                        l_part[x] *= alpha;
+                    }
+                }
+            }
+
+            // ---- P = 2^(c*S - m), row sums (fp32), packed to 16 bit ----------------------------------
+            u32x4 pk[2][4];
+            const f32x2 c2 = {c, c};
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const f32x2 nm = {-m_ref[x], -m_ref[x]};
+                float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int kb = q4 >> 1, b8 = (q4 & 1) * 8;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        f32x2 v = {s[x][kb][b8 + 2 * w], s[x][kb][b8 + 2 * w + 1]};
+                        v = __builtin_elementwise_fma(v, c2, nm);
+                        const float p0 = fast_exp2(v[0]), p1 = fast_exp2(v[1]);
+                        pk[x][q4][w] = T::pack2(p0, p1);
+                        ls0 += p0;
+                        ls1 += p1;
+                    }
+                }
+                l_part[x] += ls0 + ls1;
+            }
+
+            // ---- O^T += V^T.P^T for both query blocks: each V^T fragment feeds two MFMAs ----------
+            auto read_v = [&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr (f < 4 * G::kDBlocks) {
+                    constexpr int db = f / 4, ks = f % 4;
+                    u32x4 vf;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const u32x2 half = lds_read_tr8(
+                            smem, cur * G::kBufBytes + v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
+                        vf[2 * jj] = half[0];
+                        vf[2 * jj + 1] = half[1];
+                    }
+                    frag[f % kRing] = vf;
+                }
+            };
+            sfor<kAhead>([&](auto fc) { read_v(fc); });
+            sfor<4 * G::kDBlocks>([&](auto fc) {
+                constexpr int f = decltype(fc)::value, db = f / 4, ks = f % 4;
+                if constexpr (f == 2 * G::kDBlocks) {   // land the next tile in the other buffer
+                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds, kst);
+                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds, vst);
+                }
+                o[0][db] = T::mfma32(frag[f % kRing], pk[0][ks], o[0][db]);
+                o[1][db] = T::mfma32(frag[f % kRing], pk[1][ks], o[1][db]);
+                read_v(std::integral_constant<int, f + kAhead>{});
+            });
+            __syncthreads();
+        }
+    };
+
+    run(no);
+    float l_row[2] = {l_part[0] + swap_halves(l_part[0]), l_part[1] + swap_halves(l_part[1])};
+    {
+        // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
+        const float lim = T::id == 1 ? INFINITY : 60000.0f;
+        const bool bad = !(l_row[0] < lim) || !(l_row[1] < lim);
+        if (__syncthreads_or(bad ? 1 : 0)) {
+            run(yes);
+            l_row[0] = l_part[0] + swap_halves(l_part[0]);
+            l_row[1] = l_part[1] + swap_halves(l_part[1]);
+        }
+    }
+
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const float inv = 1.0f / l_row[x];
+        const unsigned row = q_row0 + 32u * x;
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned col = db * 32u + 8u * g + 4u * h;
+                const float a = o[x][db][4 * g] * inv, b = o[x][db][4 * g + 1] * inv;
+                const float cc = o[x][db][4 * g + 2] * inv, d = o[x][db][4 * g + 3] * inv;
+                if constexpr (kOutF32) {
+                    const f32x4 v = {a, b, cc, d};
+                    buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+                } else {
+                    const u32x2 v = {T::pack2(a, b), T::pack2(cc, d)};
+                    buf_store8(ro, (row * D + col) * 2u, v);
+                }
+            }
+    }
+    }   // persistent loop over work items
+}
+
+template <typename T, bool kOutF32>
+static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* O,
+                             int BH, int N, float scale, hipStream_t stream)
+{
+    using G = TileGeom<64>;
+    const int nqb = (N + w64::kRows - 1) / w64::kRows;
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    static const int grid_cap = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus;
+    }();
+    const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
+    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
+                       static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                       static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
+    return hipGetLastError();
+}
+
+hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
+                        int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                        hipStream_t stream)
+{
+    if (D != 64) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + w64::kRows) * 64ull * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (in_dtype == 0)
+        return out_dtype == 0 ? launch_w64<F16, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<F16, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_w64<BF16, true>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_w64<BF16, false>(Q, K, V, O, BH, N, scale, stream);
+}
+
+}  // namespace fa

@@ -41,7 +41,7 @@ def _run(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False, scale=None):
 
 
 def _algos_for(d):
-    return (0, 1, 2, 3, 4, 5, 6, 9, 10, 11) if d == 64 else ((0, 1, 2, 4) if d == 128 else (0, 1))
+    return (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13) if d == 64 else ((0, 1, 2, 4) if d == 128 else (0, 1))
 
 
 def _check(oracle, got, want, fmt, what, out_same=False, max_abs=MAX_ABS):
@@ -288,7 +288,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     # A one-hot row reproduces |V| times the rounding error of its single packed weight (the row sum is
     # taken from the unrounded fp32 p, as in the reference's fp32 statistics): 2^-9 for bf16, |V| <= ~4.5.
     tol = MAX_ABS * (2.0 if fmt == 1 else 1.0)
-    for algo in (0, 5, 6, 9, 11):
+    for algo in (0, 5, 6, 9, 11, 12):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol)
     # ragged N with the overflow in the partial last tile
@@ -297,6 +297,6 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     k2[0, n2 - 1] = q2[0, 200] * 40.0
     q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
     want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
-    for algo in (0, 5, 6, 9, 11):
+    for algo in (0, 5, 6, 9, 11, 12):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
         _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol)
