@@ -49,6 +49,10 @@ struct F16 {
         return (float)__builtin_bit_cast(_Float16, b);
     }
     static constexpr unsigned kOnes2 = 0x3C003C00u;   // two 1.0 halves
+    // acc + lo(w) + hi(w) in fp32: one v_dot2c_f32_f16 against (1, 1)
+    static __device__ __forceinline__ float sum2(unsigned w, float acc) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, w), __builtin_bit_cast(f16x2, kOnes2), acc, false);
+    }
 };
 
 struct BF16 {
@@ -69,6 +73,9 @@ struct BF16 {
     static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
     static __device__ __forceinline__ float one(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
     static constexpr unsigned kOnes2 = 0x3F803F80u;   // two 1.0 bfloat16
+    static __device__ __forceinline__ float sum2(unsigned w, float acc) {   // v_dot2c_f32_bf16
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), __builtin_bit_cast(bf16x2, kOnes2), acc, false);
+    }
 };
 
 // ---- buffer resources (wave-uniform base + byte count; out-of-range loads read 0, stores drop) --

@@ -30,8 +30,12 @@ template <int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
-constexpr int kW = 8;            // waves per workgroup
-constexpr int kRows = 64 * kW;   // 512 query rows per workgroup
+#ifndef FA_W64_WAVES
+#define FA_W64_WAVES 8
+#endif
+constexpr int kW = FA_W64_WAVES;   // waves per workgroup (4: two independent 256-row workgroups per CU)
+constexpr int kRows = 64 * kW;     // query rows per workgroup
+constexpr int kLoads = 512 / (64 * kW);   // 16-B K (and V) chunks per thread and tile
 constexpr int kAhead = 2, kRing = kAhead + 1;   // LDS fragment read-ahead
 }  // namespace w64
 
@@ -56,10 +60,15 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     const bool partial = (N % kBlockN) != 0;
 
     // staging: one 16-B chunk of K and one of V per thread and tile
-    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
-    const unsigned st_goff = srow * G::kRowBytes + sch * 16u;
-    const unsigned k_lds = G::k_off(srow, sch);
-    const unsigned v_lds = G::kTileBytes + G::v_off(srow, sch);
+    unsigned st_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
+#pragma unroll
+    for (int p = 0; p < kLoads; ++p) {
+        const unsigned idx = tid + p * 64u * kW;
+        const unsigned srow = idx / G::kChunks, sch = idx % G::kChunks;
+        st_goff[p] = srow * G::kRowBytes + sch * 16u;
+        k_lds[p] = G::k_off(srow, sch);
+        v_lds[p] = G::kTileBytes + G::v_off(srow, sch);
+    }
 
     const unsigned k_rd_row = r * G::kRowBytes;
     const unsigned k_rd_swz = G::k_swz(r);
@@ -103,7 +112,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
 
     f32x16 o[2][G::kDBlocks];
     float m_ref[2] = {0.0f, 0.0f}, l_part[2] = {0.0f, 0.0f};
-    u32x4 kst, vst;
+    u32x4 kst[kLoads], vst[kLoads];
 
     auto run = [&](auto track_c) __attribute__((always_inline)) {
         constexpr bool kTrack = decltype(track_c)::value;
@@ -113,17 +122,26 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
             l_part[x] = 0.0f;
         }
-        kst = buf_load16(rk, st_goff);
-        vst = buf_load16(rv, st_goff);
-        lds_write16(smem, k_lds, kst);
-        lds_write16(smem, v_lds, vst);
+#pragma unroll
+        for (int p = 0; p < kLoads; ++p) {
+            kst[p] = buf_load16(rk, st_goff[p]);
+            vst[p] = buf_load16(rv, st_goff[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < kLoads; ++p) {
+            lds_write16(smem, k_lds[p], kst[p]);
+            lds_write16(smem, v_lds[p], vst[p]);
+        }
         __syncthreads();
 
         for (int t = 0; t < ntiles; ++t) {
             const unsigned cur = (unsigned)t & 1u;
             // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
-            kst = buf_load16(rk, (unsigned)(t + 1) * G::kTileBytes + st_goff);
-            vst = buf_load16(rv, (unsigned)(t + 1) * G::kTileBytes + st_goff);
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                kst[p] = buf_load16(rk, (unsigned)(t + 1) * G::kTileBytes + st_goff[p]);
+                vst[p] = buf_load16(rv, (unsigned)(t + 1) * G::kTileBytes + st_goff[p]);
+            }
 
             // ---- S^T = K.Q^T for both query blocks: each K fragment feeds two MFMAs ------------
             f32x16 s[2][2];
@@ -222,8 +240,11 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             sfor<4 * G::kDBlocks>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, db = f / 4, ks = f % 4;
                 if constexpr (f == 2 * G::kDBlocks) {   // land the next tile in the other buffer
-                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds, kst);
-                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds, vst);
+#pragma unroll
+                    for (int p = 0; p < kLoads; ++p) {
+                        lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds[p], kst[p]);
+                        lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds[p], vst[p]);
+                    }
                 }
                 o[0][db] = T::mfma32(frag[f % kRing], pk[0][ks], o[0][db]);
                 o[1][db] = T::mfma32(frag[f % kRing], pk[1][ks], o[1][db]);
@@ -285,7 +306,8 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
     }();
-    const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
+    const long long cap = (long long)grid_cap * (8 / w64::kW);
+    const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
     hipLaunchKernelGGL((fa_fwd_w64_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);

@@ -1,0 +1,456 @@
+// fa_fwd_w64p.hip -- 64 query rows per wave, 512-row workgroups, half-tile rolling pipeline (gfx950, d = 64).
+//
+// The d=64 forward sits at the package power cap, where both the energy per launch
+// AND the cycle count matter (fewer cycles -> lower clock -> lower voltage -> cheaper operations).
+// fa_fwd_w64.hip showed the first half: with two 32-row query blocks per wave every K / V^T fragment
+// read from LDS feeds two MFMAs and a staged K/V tile serves 512 rows (LDS operand reads and staging
+// per flop halve), but its phase-ordered stream (QK^T, softmax, PV) needs more cycles.  This kernel
+// keeps that decomposition and restores the interleaved stream of fa_fwd_il.hip at the granularity
+// the registers allow: the unit of work is a HALF tile (32 keys x the wave's 64 query rows),
+//
+//   step u:   MFMA:  S(u+1) = K(u+1).Q^T   (8 MFMAs, 4 K fragments)
+//                    O^T   += V(u-1)^T.P(u-1)^T   (8 MFMAs, 4 V^T fragments)
+//             VALU:  P(u) = 2^(c*S(u) - m), row sums, pack             (32 scores per lane)
+//
+// so QK^T runs one unit ahead of the softmax and PV one unit behind, with two score sets and two
+// packed-P sets of 32 registers each -- the same register budget as the phase-ordered kernel.  A step
+// is written as 16 slots { MFMA ; LDS read two fragments ahead ; its slice of VALU work } with
+// scheduling fences, so program order is issue order.  The LDS fragment stream never stalls on a
+// barrier: the only tile written in iteration j is tile j+2 (ring of four 16-KB slots), and every
+// fragment read ahead across a step or iteration boundary belongs to a tile that was complete one
+// barrier earlier.
+//
+// Overflow safety, row sums, output: as fa_fwd_il.hip (optimistic pass against a fixed reference
+// max + exact detection + tracked re-run; fp32 v_add sums; persistent XCD-aware grid).
+#include "fa_tile.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace fa {
+
+namespace w64p {
+template <int... I, typename F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+constexpr int kW = 8;              // waves per workgroup
+constexpr int kRows = 64 * kW;     // query rows per workgroup
+constexpr int kSlots = 4;          // LDS ring: tiles j-1 .. j+2
+constexpr int kAhead = 2;          // fragments read ahead of their MFMAs
+constexpr int kRing = 4;           // fragment registers (8 fragments per step: the phase repeats)
+#ifndef FA_W64P_SETPRIO
+#define FA_W64P_SETPRIO 0
+#endif
+#ifndef FA_W64P_DOT2
+#define FA_W64P_DOT2 0             // row sums: one v_dot2c per packed pair (sum of the ROUNDED p, the values PV uses) instead of two v_add
+#endif
+#ifndef FA_W64P_STAGE_SLOT
+#define FA_W64P_STAGE_SLOT 8       // MFMA slot of the second step in front of which tile j+2 is written to LDS
+#endif
+}  // namespace w64p
+
+template <typename T, bool kOutF32>
+__global__ __launch_bounds__(64 * w64p::kW, 2)
+void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                        const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                        int N, int nqb, float scale_log2e, unsigned total_wg)
+{
+    using namespace w64p;
+    constexpr int D = 64;
+    using G = TileGeom<D>;
+    constexpr unsigned kSlotBytes = G::kBufBytes;   // [K tile][V tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const unsigned tid  = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane = tid & 63u;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const float c = fabsf(scale_log2e);
+    const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
+    const int ntiles = (N + kBlockN - 1) / kBlockN;
+    const bool partial = (N % kBlockN) != 0;
+
+    // staging: one 16-B chunk of K and one of V per thread and tile
+    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
+    const unsigned st_goff = srow * G::kRowBytes + sch * 16u;
+    const unsigned k_lds = G::k_off(srow, sch);
+    const unsigned v_lds = G::kTileBytes + G::v_off(srow, sch);
+
+    const unsigned k_rd_row = r * G::kRowBytes;
+    const unsigned k_rd_swz = G::k_swz(r);
+    const unsigned i16 = lane & 15u, vq = i16 >> 2, vp = i16 & 3u, vg = (lane >> 4) & 1u;
+    unsigned v_rd[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        v_rd[par] = G::kTileBytes + h * G::kDBlocks * 256u + ((vq ^ par) << 6) + vg * 32u + vp * 8u;
+
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    constexpr float kHeadroom = 4.0f;
+    const std::true_type yes{};
+    const std::false_type no{};
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+
+    const unsigned nwg = total_wg;
+    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    if (bid != blockIdx.x) __syncthreads();
+    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const unsigned bh = wgid / (unsigned)nqb;
+    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+    const unsigned q_row0 = qb * kRows + wave * 64u + r;   // query block 0; block 1 is 32 rows further
+
+    u32x4 qf[2][G::kKSteps];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int s = 0; s < G::kKSteps; ++s) {
+            u32x4 raw = buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) raw[w] ^= q_flip;
+            qf[x][s] = raw;
+        }
+
+    f32x16 o[2][G::kDBlocks];
+    float m_ref[2] = {0.0f, 0.0f}, l_part[2] = {0.0f, 0.0f};
+    u32x4 kst, vst;
+    u32x4 frag[kRing];
+
+    // LDS fragment addresses.  A K fragment of unit (tile slot offset `so`, key block kb), k-step ks;
+    // a V^T fragment of unit (so, kb), head-dim block db, 16-key step ks2.
+    auto read_kf = [&](unsigned so, int kb, int ks) -> u32x4 {
+        return lds_read16(smem, so + kb * 32u * G::kRowBytes + k_rd_row + (((2u * ks + h) ^ k_rd_swz) << 4));
+    };
+    auto read_vf = [&](unsigned so, int kb, int db, int ks2) -> u32x4 {
+        u32x4 vf;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const u32x2 half = lds_read_tr8(smem, so + v_rd[db & 1] + ((4u * (2 * kb + ks2) + 2u * jj) * G::kDBlocks + db) * 256u);
+            vf[2 * jj] = half[0];
+            vf[2 * jj + 1] = half[1];
+        }
+        return vf;
+    };
+    // fragment f (0..7) of a step: even f -> K fragment ks = f/2 of the QK^T unit, odd f -> V^T
+    // fragment (db = f/4, ks2 = (f/2)&1) of the PV unit
+    auto read_frag = [&](auto fc, unsigned so_q, int kb_q, unsigned so_v, int kb_v) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, kb_q, f >> 1);
+        else frag[f % kRing] = read_vf(so_v, kb_v, f >> 2, (f >> 1) & 1);
+    };
+    auto mask_unit = [&](int tile, int kb, f32x16 (&s)[2]) {   // keys >= N -> -inf (p = 0)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = tile * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                if (key >= N) s[x][i] = -INFINITY;
+            }
+    };
+    auto row_max = [&](const f32x16& s) -> float {   // over this lane's 16 keys, both half-waves
+        float a = max3(s[0], s[1], s[2]), b = max3(s[3], s[4], s[5]);
+        a = max3(a, s[6], s[7]);
+        b = max3(b, s[8], s[9]);
+        a = max3(a, s[10], s[11]);
+        b = max3(b, s[12], s[13]);
+        a = max3(a, s[14], s[15]);
+        a = fmaxf(a, b) * c;
+        return fmaxf(a, swap_halves(a));
+    };
+
+    // One step of the optimistic pass.  kb = key block of the unit being softmaxed (s_cur = its raw
+    // scores -> pk_cur); the QK^T unit is (so_q, 1-kb) -> s_nxt, the PV unit (so_v, 1-kb) <- pk_prev.
+    // `so_nq/so_nv`: slot offsets of the NEXT step's QK^T / PV units, for the fragments read ahead.
+    auto step = [&](auto kb_c, int tile, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[2][2],
+                    u32x4 (&pk_cur)[2][2], unsigned so_q, unsigned so_v, unsigned so_nq, unsigned so_nv,
+                    unsigned so_land) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kb_c)::value, ko = 1 - kb;
+        if (partial && tile + 1 == ntiles) mask_unit(tile, kb, s_cur);
+
+        constexpr int kSteps = 16;   // VALU pair-steps: pairs 0-7 query block 0, 8-15 query block 1
+        const f32x2 c2 = {c, c};
+        const f32x2 nm[2] = {{-m_ref[0], -m_ref[0]}, {-m_ref[1], -m_ref[1]}};
+        float ls[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        auto fma_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = j >> 3, e = 2 * (j & 7);
+            f32x2 v = {s_cur[x][e], s_cur[x][e + 1]};
+            v = __builtin_elementwise_fma(v, c2, nm[x]);
+            s_cur[x][e] = v[0];
+            s_cur[x][e + 1] = v[1];
+        };
+        auto exp_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = j >> 3, e = 2 * (j & 7);
+            s_cur[x][e] = fast_exp2(s_cur[x][e]);
+            s_cur[x][e + 1] = fast_exp2(s_cur[x][e + 1]);
+        };
+        auto fin_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = j >> 3, e = 2 * (j & 7);
+            const unsigned w = T::pack2(s_cur[x][e], s_cur[x][e + 1]);
+            pk_cur[x][(j & 7) >> 2][j & 3] = w;
+            if constexpr (FA_W64P_DOT2) {
+                ls[x][j & 1] = T::sum2(w, ls[x][j & 1]);
+            } else {
+                ls[x][0] += s_cur[x][e];
+                ls[x][1] += s_cur[x][e + 1];
+            }
+        };
+        auto valu_step = [&](auto jc) {   // skewed: nothing waits on the instruction before it
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 2 < kSteps) fma_pair(std::integral_constant<int, j + 2>{});
+            if constexpr (j + 1 < kSteps) exp_pair(std::integral_constant<int, j + 1>{});
+            fin_pair(jc);
+        };
+        auto issue_mfma = [&](auto ic) {
+            constexpr int i = decltype(ic)::value, f = i >> 1, x = i & 1;
+            if constexpr ((f & 1) == 0) {
+                constexpr int ks = f >> 1;
+                s_nxt[x] = T::mfma32(frag[f % kRing], qf[x][ks], ks == 0 ? zero16 : s_nxt[x]);
+            } else {
+                constexpr int db = f >> 2, ks2 = (f >> 1) & 1;
+                o[x][db] = T::mfma32(frag[f % kRing], pk_prev[x][ks2], o[x][db]);
+            }
+        };
+
+        fma_pair(c0{});
+        fma_pair(c1{});
+        exp_pair(c0{});
+        sfor<16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kb == 1 && i == FA_W64P_STAGE_SLOT) {   // land tile j+2 (requested at the top of the iteration)
+                lds_write16(smem, so_land + k_lds, kst);
+                lds_write16(smem, so_land + v_lds, vst);
+            }
+            if constexpr (FA_W64P_SETPRIO) __builtin_amdgcn_s_setprio(1);
+            issue_mfma(ic);
+            if constexpr ((i & 1) == 1) {   // the fragment just consumed twice is free: read two ahead
+                constexpr int f = (i >> 1) + kAhead;
+                if constexpr (f < 8) read_frag(std::integral_constant<int, f>{}, so_q, ko, so_v, ko);
+                else read_frag(std::integral_constant<int, f - 8>{}, so_nq, kb, so_nv, kb);
+            }
+            if constexpr (FA_W64P_SETPRIO) __builtin_amdgcn_s_setprio(0);
+            valu_step(ic);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        l_part[0] += ls[0][0] + ls[0][1];
+        l_part[1] += ls[1][0] + ls[1][1];
+    };
+
+    // One step of the tracked (fallback) pass: same data flow in plain program order, with the lazy
+    // running max per unit.  Speed is irrelevant here.
+    auto step_tracked = [&](auto kb_c, int tile, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[2][2],
+                            u32x4 (&pk_cur)[2][2], unsigned so_q, unsigned so_v, unsigned so_land) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kb_c)::value, ko = 1 - kb;
+        // O^T += V(u-1)^T.P(u-1)^T first: P(u-1) is in the scale of the current reference max
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const u32x4 vf = read_vf(so_v, ko, db, ks2);
+                o[0][db] = T::mfma32(vf, pk_prev[0][ks2], o[0][db]);
+                o[1][db] = T::mfma32(vf, pk_prev[1][ks2], o[1][db]);
+            }
+        if (partial && tile + 1 == ntiles) mask_unit(tile, kb, s_cur);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float tmax = row_max(s_cur[x]);
+            if (__any(tmax - m_ref[x] > kThr)) {
+                const float m_new = fmaxf(tmax, m_ref[x]);
+                const float alpha = fast_exp2(m_ref[x] - m_new);
+                m_ref[x] = m_new;
+#pragma unroll
+                for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[x][db][i] *= alpha;
+                l_part[x] *= alpha;
+            }
+            float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = fast_exp2(fmaf(s_cur[x][e], c, -m_ref[x]));
+                const float p1 = fast_exp2(fmaf(s_cur[x][e + 1], c, -m_ref[x]));
+                const unsigned w = T::pack2(p0, p1);
+                pk_cur[x][e >> 3][(e >> 1) & 3] = w;
+                if constexpr (FA_W64P_DOT2) {
+                    ls0 = T::sum2(w, ls0);
+                } else {
+                    ls0 += p0;
+                    ls1 += p1;
+                }
+            }
+            l_part[x] += ls0 + ls1;
+        }
+#pragma unroll
+        for (int ks = 0; ks < G::kKSteps; ++ks) {
+            const u32x4 kf = read_kf(so_q, ko, ks);
+            s_nxt[0] = T::mfma32(kf, qf[0][ks], ks == 0 ? zero16 : s_nxt[0]);
+            s_nxt[1] = T::mfma32(kf, qf[1][ks], ks == 0 ? zero16 : s_nxt[1]);
+        }
+        if constexpr (kb == 1) {
+            lds_write16(smem, so_land + k_lds, kst);
+            lds_write16(smem, so_land + v_lds, vst);
+        }
+    };
+
+    auto run = [&](auto track_c) __attribute__((always_inline)) {
+        constexpr bool kTrack = decltype(track_c)::value;
+        f32x16 sA[2], sB[2];
+        u32x4 pkA[2][2], pkB[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
+            l_part[x] = 0.0f;
+            pkB[x][0] = pkB[x][1] = zero4;   // "P(-1)" = 0 against the zeroed V of ring slot 3
+        }
+        // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ------------
+        {
+            const u32x4 k0 = buf_load16(rk, st_goff), v0 = buf_load16(rv, st_goff);
+            const u32x4 k1 = buf_load16(rk, G::kTileBytes + st_goff), v1 = buf_load16(rv, G::kTileBytes + st_goff);
+            lds_write16(smem, 3u * kSlotBytes + v_lds, zero4);
+            lds_write16(smem, k_lds, k0);
+            lds_write16(smem, v_lds, v0);
+            lds_write16(smem, kSlotBytes + k_lds, k1);
+            lds_write16(smem, kSlotBytes + v_lds, v1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < G::kKSteps; ++ks) {   // S(unit 0)
+            const u32x4 kf = read_kf(0u, 0, ks);
+            sA[0] = T::mfma32(kf, qf[0][ks], ks == 0 ? zero16 : sA[0]);
+            sA[1] = T::mfma32(kf, qf[1][ks], ks == 0 ? zero16 : sA[1]);
+        }
+        {
+            // reference max from the first 32 keys (masked copy when N < 32; the step masks again)
+            f32x16 s0[2] = {sA[0], sA[1]};
+            if (partial && ntiles == 1) mask_unit(0, 0, s0);
+            m_ref[0] = row_max(s0[0]) + (kTrack ? 0.0f : kHeadroom);
+            m_ref[1] = row_max(s0[1]) + (kTrack ? 0.0f : kHeadroom);
+        }
+        if constexpr (!kTrack) {   // fragments 0,1 of the first step: K(tile 0, kb 1), V("tile -1")
+            read_frag(c0{}, 0u, 1, 3u * kSlotBytes, 1);
+            read_frag(c1{}, 0u, 1, 3u * kSlotBytes, 1);
+        }
+
+        for (int j = 0; j < ntiles; ++j) {
+            const unsigned so_m1 = ((unsigned)(j + 3) & 3u) * kSlotBytes, so_0 = ((unsigned)j & 3u) * kSlotBytes;
+            const unsigned so_p1 = ((unsigned)(j + 1) & 3u) * kSlotBytes, so_p2 = ((unsigned)(j + 2) & 3u) * kSlotBytes;
+            // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
+            kst = buf_load16(rk, (unsigned)(j + 2) * G::kTileBytes + st_goff);
+            vst = buf_load16(rv, (unsigned)(j + 2) * G::kTileBytes + st_goff);
+            if constexpr (kTrack) {
+                step_tracked(c0{}, j, sA, sB, pkB, pkA, so_0, so_m1, so_p2);
+                step_tracked(c1{}, j, sB, sA, pkA, pkB, so_p1, so_0, so_p2);
+            } else {
+                //   kb 0: softmax (j,0);  QK^T (j,1);    PV (j-1,1);  next step: QK^T (j+1,0), PV (j,0)
+                //   kb 1: softmax (j,1);  QK^T (j+1,0);  PV (j,0);    next step: QK^T (j+1,1), PV (j,1)
+                step(c0{}, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p2);
+                step(c1{}, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p2);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: O^T += V(last tile, kb 1)^T.P^T ---------------------------------------------
+        {
+            const unsigned so = ((unsigned)(ntiles - 1) & 3u) * kSlotBytes;
+#pragma unroll
+            for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+                    const u32x4 vf = read_vf(so, 1, db, ks2);
+                    o[0][db] = T::mfma32(vf, pkB[0][ks2], o[0][db]);
+                    o[1][db] = T::mfma32(vf, pkB[1][ks2], o[1][db]);
+                }
+        }
+    };
+
+    run(no);
+    float l_row[2] = {l_part[0] + swap_halves(l_part[0]), l_part[1] + swap_halves(l_part[1])};
+    {
+        // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
+        const float lim = T::id == 1 ? INFINITY : 60000.0f;
+        const bool bad = !(l_row[0] < lim) || !(l_row[1] < lim);
+        if (__syncthreads_or(bad ? 1 : 0)) {
+            run(yes);
+            l_row[0] = l_part[0] + swap_halves(l_part[0]);
+            l_row[1] = l_part[1] + swap_halves(l_part[1]);
+        }
+    }
+
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const float inv = 1.0f / l_row[x];
+        const unsigned row = q_row0 + 32u * x;
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned col = db * 32u + 8u * g + 4u * h;
+                const float a = o[x][db][4 * g] * inv, b = o[x][db][4 * g + 1] * inv;
+                const float cc = o[x][db][4 * g + 2] * inv, d = o[x][db][4 * g + 3] * inv;
+                if constexpr (kOutF32) {
+                    const f32x4 v = {a, b, cc, d};
+                    buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+                } else {
+                    const u32x2 v = {T::pack2(a, b), T::pack2(cc, d)};
+                    buf_store8(ro, (row * D + col) * 2u, v);
+                }
+            }
+    }
+    }   // persistent loop over work items
+}
+
+template <typename T, bool kOutF32>
+static hipError_t launch_w64p(const void* Q, const void* K, const void* V, void* O,
+                              int BH, int N, float scale, hipStream_t stream)
+{
+    using G = TileGeom<64>;
+    const int nqb = (N + w64p::kRows - 1) / w64p::kRows;
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    static const int grid_cap = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus;
+    }();
+    const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64p_kernel<T, kOutF32>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, w64p::kSlots * G::kBufBytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((fa_fwd_w64p_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64p::kW),
+                       w64p::kSlots * G::kBufBytes, stream,
+                       static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+                       static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
+    return hipGetLastError();
+}
+
+hipError_t w64p_dispatch(const void* Q, const void* K, const void* V, void* O,
+                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                         hipStream_t stream)
+{
+    if (D != 64) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + w64p::kRows + 3 * kBlockN) * 64ull * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (in_dtype == 0)
+        return out_dtype == 0 ? launch_w64p<F16, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64p<F16, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_w64p<BF16, true>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_w64p<BF16, false>(Q, K, V, O, BH, N, scale, stream);
+}
+
+}  // namespace fa
