@@ -8,6 +8,9 @@
 // operands): the same arithmetic for 14 % less energy.  Each wave therefore treats its 32 query rows
 // as two 16-row blocks that share every K and V fragment read from LDS (LDS traffic is unchanged
 // against the 32x32x16 kernel; only the number of MFMA instructions doubles).
+// MEASURED OUTCOME: no gain in the full kernel -- 0.613 ms vs 0.612 ms (fp16), 0.590 vs 0.580 (bf16)
+// at B8 H16 N4096: twice the MFMA issue slots and accumulator traffic eat the 14 %.  Kept selectable
+// (FA_ALGO_IL2X16) and parity-tested; not the default.
 //
 // Lane roles (lane = 16*g + c): for query block qb the accumulator of S^T = K.Q^T has query
 // 16*qb + c on the lane and keys 16*kb + 4*g + i in register i of key block kb; four lanes

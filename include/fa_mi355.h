@@ -35,6 +35,10 @@ extern "C" {
 #define FA_ALGO_INTERLEAVED     5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
 #define FA_ALGO_INTERLEAVED_2WG 6 /* the same with 128-row workgroups, two per CU, D = 64 */
 #define FA_ALGO_TLP3            9 /* simple per-wave stream, three 128-row workgroups per CU, D = 64 */
+#define FA_ALGO_IL16           11 /* 16 waves x 16 rows on v_mfma_f32_16x16x32, D = 64 */
+#define FA_ALGO_IL2X16         12 /* 8 waves x two 16-row blocks sharing K/V fragments, 16x16x32, D = 64 */
+#define FA_ALGO_W64            13 /* 64 query rows per wave, 512-row workgroups, phase-ordered stream, D = 64 */
+#define FA_ALGO_W64P           14 /* the same with a half-tile rolling pipeline, D = 64 */
 /* 7, 8, 10: experimental occupancy variants kept for A/B timing (fp16, d=64). */
 
 /* General-shape forward.  Replaces
