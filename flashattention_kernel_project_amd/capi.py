@@ -19,6 +19,7 @@ SYMBOLS = (
     "flashattn_forward_wmma",
     "fa_forward",
     "fa_forward_ex",
+    "fa_forward_causal",
     "flashattn_streaming_16x16_mw",
     "flashattn_streaming_16x16_mw_kt",
     "fa_mi355_version",
@@ -73,6 +74,7 @@ def lib() -> C.CDLL:
         L.flashattn_forward_wmma.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]
         L.fa_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, vp]
         L.fa_forward_ex.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, i, vp]
+        L.fa_forward_causal.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, i, vp]
         L.flashattn_streaming_16x16_mw.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         L.flashattn_streaming_16x16_mw_kt.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         for s in SYMBOLS[:-1]:

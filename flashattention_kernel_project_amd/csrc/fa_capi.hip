@@ -6,6 +6,9 @@ namespace fa {
 hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                             int algo, hipStream_t stream);
+hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
+                                   int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                                   int algo, hipStream_t stream);
 hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
                                 int num_batches, int seq_len, float scale, bool k_transposed,
                                 hipStream_t stream);
@@ -54,6 +57,16 @@ int fa_forward(const void* Q, const void* K, const void* V, void* O,
                int in_dtype, int out_dtype, void* stream)
 {
     return fa_forward_ex(Q, K, V, O, B, H, N, d, scale, in_dtype, out_dtype, FA_ALGO_AUTO, stream);
+}
+
+int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
+                      int B, int H, int N, int d, float scale,
+                      int in_dtype, int out_dtype, int algo, void* stream)
+{
+    if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
+    if (out_dtype != FA_OUT_F32 && out_dtype != FA_OUT_SAME) return (int)hipErrorInvalidValue;
+    return (int)fa::forward_causal_dispatch(Q, K, V, O, B * H, N, d, scale, in_dtype, out_dtype, algo,
+                                            static_cast<hipStream_t>(stream));
 }
 
 int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,

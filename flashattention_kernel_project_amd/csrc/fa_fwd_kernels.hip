@@ -34,7 +34,11 @@ namespace fa {
 // W = waves per workgroup (32 query rows each), kOcc = workgroups' waves per SIMD the register
 // budget is held to (W = 8, kOcc = 2: one 256-row workgroup per CU; W = 4, kOcc = 3: three
 // independent 128-row workgroups per CU, so the waves sharing a SIMD are never barrier-coupled).
-template <typename T, int D, bool kOutF32, int W = kWaves, int kOcc = 2>
+// kCausal: query row i attends to keys 0..i only.  A workgroup stops at the tile that holds its last
+// row's diagonal, a wave skips (but still stages and synchronises) tiles that lie wholly above its 32
+// rows, and the tiles the diagonal crosses get a per-element mask; query blocks are walked last to
+// first so that the longest ones start first.
+template <typename T, int D, bool kOutF32, int W = kWaves, int kOcc = 2, bool kCausal = false>
 __global__ __launch_bounds__(64 * W, kOcc)
 void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                    const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -48,7 +52,7 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
     const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
     const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const unsigned bh = wgid / (unsigned)nqb;
-    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const unsigned qb = kCausal ? (unsigned)nqb - 1u - (wgid - bh * (unsigned)nqb) : wgid - bh * (unsigned)nqb;
 
     const unsigned tid  = threadIdx.x;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,7 +66,8 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
 
     constexpr int kLoadsW = (kBlockN * G::kChunks) / (64 * W);
-    const unsigned q_row = qb * (32u * W) + wave * 32u + r;
+    const unsigned wave_row0 = qb * (32u * W) + wave * 32u;   // first query row of this wave
+    const unsigned q_row = wave_row0 + r;
 
     // ---- Q^T fragments (B operand of S^T = K.Q^T), resident for the whole kernel ---------------
     // c = |scale|*log2(e) is applied to the fp32 scores; a negative scale flips Q's sign bits so
@@ -129,7 +134,11 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
     float m_ref = 0.0f;    // reference max of this lane's query row, in log2 units (c*S)
     float l_part = 0.0f;   // this half-wave's share of the row sum
 
-    const int ntiles = (N + kBlockN - 1) / kBlockN;
+    int ntiles = (N + kBlockN - 1) / kBlockN;
+    if constexpr (kCausal) {   // tiles up to the diagonal of the workgroup's last (existing) row
+        const unsigned last_row = min((unsigned)N - 1u, qb * (32u * W) + 32u * W - 1u);
+        ntiles = min(ntiles, (int)(last_row / kBlockN) + 1);
+    }
 
     stage_load(0);
     stage_write(0);
@@ -139,6 +148,8 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
         const unsigned cur = t & 1u;
         const char* kbuf = smem + cur * G::kBufBytes;
         if (t + 1 < ntiles) stage_load((t + 1) * kBlockN);
+        // causal: tiles wholly above this wave's rows contribute nothing (wave-uniform; tile 0 never is)
+        if (!kCausal || (unsigned)(t * kBlockN) <= wave_row0 + 31u) {
 
         // ---- S^T = K.Q^T (raw fp32 scores) ------------------------------------------------
         f32x16 s[2];
@@ -161,6 +172,17 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
                     const int key = t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
                     if (key >= N) s[kb][i] = -INFINITY;
                 }
+        }
+        if constexpr (kCausal) {   // tiles the diagonal crosses: keys after the query -> -inf
+            if ((unsigned)(t * kBlockN) + (unsigned)kBlockN - 1u > wave_row0) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned key = (unsigned)(t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2)) + 4u * h;
+                        if (key > q_row) s[kb][i] = -INFINITY;
+                    }
+            }
         }
 
         // ---- tile max vs the reference max; raise the reference only when needed ----------------
@@ -221,6 +243,7 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
                 o[db] = T::mfma32(vf, pk[ks], o[db]);
             }
         }
+        }   // wave has work in this tile
 
         if (t + 1 < ntiles) stage_write(cur ^ 1u);
         __syncthreads();
@@ -261,7 +284,7 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 constexpr int kGenMaxD = 256;
 
-template <typename T, bool kOutF32>
+template <typename T, bool kOutF32, bool kCausal = false>
 __global__ __launch_bounds__(64)
 void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                            const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -288,7 +311,8 @@ void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
     for (int db = 0; db < kGenMaxD / 16; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l_part = 0.0f;
 
-    for (int kv0 = 0; kv0 < N; kv0 += 16) {
+    const int kv_end = kCausal ? min(N, (int)(qb * 16u) + 16) : N;   // causal: up to the wave's last diagonal
+    for (int kv0 = 0; kv0 < kv_end; kv0 += 16) {
         // A operand: lane (c16,g4) holds K[kv0 + c16][16s + 4g4 + 0..3]
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -301,7 +325,8 @@ void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
         // s4[i] = S[q_row][kv0 + 4*g4 + i]; to the log2 domain in fp32
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            s4[i] = (kv0 + 4 * (int)g4 + i >= N) ? -INFINITY : s4[i] * scale_log2e;
+            s4[i] = (kv0 + 4 * (int)g4 + i >= N || (kCausal && (unsigned)(kv0 + 4 * (int)g4 + i) > q_row))
+                        ? -INFINITY : s4[i] * scale_log2e;
         float tmax = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -360,12 +385,12 @@ void fa_fwd_generic_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __re
 // ---------------------------------------------------------------------------------------------
 namespace fa {
 
-template <typename T, int D, bool kOutF32, int W = kWaves, int kOcc = 2>
+template <typename T, int D, bool kOutF32, int W = kWaves, int kOcc = 2, bool kCausal = false>
 static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void* O,
                                int BH, int N, float scale, hipStream_t stream)
 {
     using G = TileGeom<D>;
-    auto kern = fa_fwd_kernel<T, D, kOutF32, W, kOcc>;
+    auto kern = fa_fwd_kernel<T, D, kOutF32, W, kOcc, kCausal>;
     static bool attr_set = false;   // dyn-LDS opt-in is per function, cached (SURVEY 8(b) "Ownership")
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -382,14 +407,14 @@ static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void
     return hipGetLastError();
 }
 
-template <typename T, bool kOutF32>
+template <typename T, bool kOutF32, bool kCausal = false>
 static hipError_t launch_generic(const void* Q, const void* K, const void* V, void* O,
                                  int BH, int N, int D, float scale, hipStream_t stream)
 {
     const int nqb = (N + 15) / 16;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((fa_fwd_generic_kernel<T, kOutF32>), dim3((unsigned)nwg), dim3(64), 0, stream,
+    hipLaunchKernelGGL((fa_fwd_generic_kernel<T, kOutF32, kCausal>), dim3((unsigned)nwg), dim3(64), 0, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, D, nqb, scale * kLog2e);
     return hipGetLastError();
@@ -405,6 +430,18 @@ static hipError_t dispatch_d(const void* Q, const void* K, const void* V, void* 
         if (algo == 2) return hipErrorInvalidValue;
     }
     return launch_generic<T, kOutF32>(Q, K, V, O, BH, N, D, scale, stream);
+}
+
+template <typename T, bool kOutF32>
+static hipError_t dispatch_causal_d(const void* Q, const void* K, const void* V, void* O,
+                                    int BH, int N, int D, float scale, int algo, hipStream_t stream)
+{
+    if (algo != 1) {
+        if (D == 64)  return launch_tiled<T, 64, kOutF32, kWaves, 2, true>(Q, K, V, O, BH, N, scale, stream);
+        if (D == 128) return launch_tiled<T, 128, kOutF32, kWaves, 2, true>(Q, K, V, O, BH, N, scale, stream);
+        if (algo == 2) return hipErrorInvalidValue;
+    }
+    return launch_generic<T, kOutF32, true>(Q, K, V, O, BH, N, D, scale, stream);
 }
 
 hipError_t pipe_dispatch(const void* Q, const void* K, const void* V, void* O,
@@ -475,6 +512,24 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (in_dtype == 1)
         return out_dtype == 0 ? dispatch_d<BF16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
                               : dispatch_d<BF16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);
+    return hipErrorInvalidValue;
+}
+
+// Causal forward (not a reference entry point).  algo: 0 auto, 1 generic, 2 tiled.
+hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
+                                   int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                                   int algo, hipStream_t stream)
+{
+    if (!Q || !K || !V || !O) return hipErrorInvalidValue;
+    if (BH <= 0 || N <= 0 || D <= 0 || D % 16 != 0 || D > kGenMaxD) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (algo < 0 || algo > 2) return hipErrorInvalidValue;
+    if (in_dtype == 0)
+        return out_dtype == 0 ? dispatch_causal_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
+                              : dispatch_causal_d<F16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);
+    if (in_dtype == 1)
+        return out_dtype == 0 ? dispatch_causal_d<BF16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
+                              : dispatch_causal_d<BF16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);
     return hipErrorInvalidValue;
 }
 

@@ -55,9 +55,10 @@ def flashattn_forward_wmma(Q, K, V, O, BH: int, N: int, D: int, scale: float, st
 
 
 def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = capi.ALGO_AUTO,
-               out=None, stream=None):
+               out=None, stream=None, causal: bool = False):
     """Attention forward on [B,H,N,d] (or [BH,N,d]) fp16/bf16 device tensors.
-    out_dtype: torch.float32 (the reference's output type, default) or the input dtype."""
+    out_dtype: torch.float32 (the reference's output type, default) or the input dtype.
+    causal: query row i attends to keys 0..i (fa_forward_causal; algo AUTO/GENERIC/TILED only)."""
     import torch
     if q.dim() == 3:
         B, (H, N, d) = 1, q.shape
@@ -85,11 +86,12 @@ def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = 
     if scale is None:
         scale = 1.0 / math.sqrt(d)
     dts = (torch.float16, torch.bfloat16)
-    code = capi.lib().fa_forward_ex(
+    fn_name = "fa_forward_causal" if causal else "fa_forward_ex"
+    code = getattr(capi.lib(), fn_name)(
         _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts),
         _dev_ptr(out, "out", (out_dtype,)), B, H, N, d, float(scale), in_dt, out_dt, algo,
         _stream_ptr(stream))
-    capi.check("fa_forward_ex", code)
+    capi.check(fn_name, code)
     return out
 
 

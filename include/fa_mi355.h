@@ -62,6 +62,15 @@ int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
                   int B, int H, int N, int d, float scale,
                   int in_dtype, int out_dtype, int algo, void* stream);
 
+/* Causal (lower-triangular) self-attention: query row i attends to keys 0..i.  Same layouts and
+ * dtypes as fa_forward.  NOT a reference entry point: the reference has no mask; this is the first
+ * "next" row of SURVEY.md 8(f) (cf. the runtime-M tail masking of
+ * flashattn_warp_spc/flashattn_streaming_16x16_mw_v12d.cu:100-135).  algo: FA_ALGO_AUTO,
+ * FA_ALGO_GENERIC or FA_ALGO_TILED (D in {64,128}). */
+int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
+                      int B, int H, int N, int d, float scale,
+                      int in_dtype, int out_dtype, int algo, void* stream);
+
 /* 16x16 streaming family.  Replaces
  *   flashattn_streaming_16x16_kernel_mw(const __half* Q, const __half* K, const __half* V, float* O,
  *                                       int num_batches, int seq_len, float scale)

@@ -78,9 +78,30 @@ static void one_row_f64(const float* q, const float* Kb, const float* Vb, float*
     for (int c = 0; c < D; ++c) o[c] = (float)od[c];
 }
 
+static void forward_rows_impl(const float* Q, const float* K, const float* V, float* O,
+                              int BH, int N, int D, float scale, int accum, int nthreads,
+                              int bh0, int bh1, int row0, int row1, int causal);
+
 void fa_oracle_forward_rows(const float* Q, const float* K, const float* V, float* O,
                             int BH, int N, int D, float scale, int accum, int nthreads,
                             int bh0, int bh1, int row0, int row1)
+{
+    forward_rows_impl(Q, K, V, O, BH, N, D, scale, accum, nthreads, bh0, bh1, row0, row1, 0);
+}
+
+/* Causal (lower-triangular) variant: query row i attends to keys 0..i, i.e. it is the
+ * non-causal row oracle over the key prefix of length i+1.  Not in the reference (SURVEY 8(f)
+ * rank 1): pinned only through that identity with the pinned non-causal oracle. */
+void fa_oracle_forward_causal_rows(const float* Q, const float* K, const float* V, float* O,
+                                   int BH, int N, int D, float scale, int accum, int nthreads,
+                                   int bh0, int bh1, int row0, int row1)
+{
+    forward_rows_impl(Q, K, V, O, BH, N, D, scale, accum, nthreads, bh0, bh1, row0, row1, 1);
+}
+
+static void forward_rows_impl(const float* Q, const float* K, const float* V, float* O,
+                              int BH, int N, int D, float scale, int accum, int nthreads,
+                              int bh0, int bh1, int row0, int row1, int causal)
 {
     if (BH <= 0 || N <= 0 || D <= 0) return;
     if (bh0 < 0) bh0 = 0;
@@ -106,8 +127,9 @@ void fa_oracle_forward_rows(const float* Q, const float* K, const float* V, floa
             const size_t base = (size_t)bh * N * D;
             const float* q = Q + base + (size_t)i * D;
             float* o = O + base + (size_t)i * D;
-            if (accum == 1) one_row_f64(q, K + base, V + base, o, N, D, scale, w, od);
-            else            one_row_f32(q, K + base, V + base, o, N, D, scale, w);
+            const int nkeys = causal ? i + 1 : N;
+            if (accum == 1) one_row_f64(q, K + base, V + base, o, nkeys, D, scale, w, od);
+            else            one_row_f32(q, K + base, V + base, o, nkeys, D, scale, w);
         }
         free(w);
         free(od);

@@ -33,6 +33,12 @@ void fa_oracle_forward_rows(const float* Q, const float* K, const float* V, floa
                             int BH, int N, int D, float scale, int accum, int nthreads,
                             int bh0, int bh1, int row0, int row1);
 
+/* Causal variant (query row i sees keys 0..i): the row oracle above over the key prefix i+1.
+ * Not a reference function; see the .c file. */
+void fa_oracle_forward_causal_rows(const float* Q, const float* K, const float* V, float* O,
+                                   int BH, int N, int D, float scale, int accum, int nthreads,
+                                   int bh0, int bh1, int row0, int row1);
+
 /* 16x16 streaming family oracle: Q [B,16,16], K [B,16,L] (k-major), V [B,L,16], O [B,16,16];
  * softmax normalised as 1/(sum + 1e-6), running max seeded with -1e30
  * (Streaming_FlashAttention_Forward_Kernel/flashattn_streaming_16x16_mw.cu:252-317). */

@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(_LIB)
         L.fa_oracle_forward.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         L.fa_oracle_forward_rows.argtypes = L.fa_oracle_forward.argtypes + [C.c_int] * 4
+        L.fa_oracle_forward_causal_rows.argtypes = L.fa_oracle_forward_rows.argtypes
         L.fa_oracle_streaming_16x16.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float]
         L.fa_oracle_transpose_k_16.argtypes = [_fp, _fp, C.c_int, C.c_int]
         L.fa_oracle_fill.argtypes = [_fp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
@@ -109,7 +110,7 @@ def decode16(u: np.ndarray, fmt: int) -> np.ndarray:
     return out
 
 
-def forward(q, k, v, scale=None, accum: int = 0, nthreads: int = 1, bh_range=None, row_range=None):
+def forward(q, k, v, scale=None, accum: int = 0, nthreads: int = 1, bh_range=None, row_range=None, causal: bool = False):
     """Naive 3-loop attention forward on [BH,N,D] fp32 arrays (already 16-bit-rounded)."""
     q = np.ascontiguousarray(q, np.float32)
     k = np.ascontiguousarray(k, np.float32)
@@ -120,8 +121,8 @@ def forward(q, k, v, scale=None, accum: int = 0, nthreads: int = 1, bh_range=Non
     o = np.zeros_like(q)
     b0, b1 = bh_range if bh_range else (0, bh)
     r0, r1 = row_range if row_range else (0, n)
-    lib().fa_oracle_forward_rows(_f(q), _f(k), _f(v), _f(o), bh, n, d, float(scale), accum, nthreads,
-                                 b0, b1, r0, r1)
+    fn = lib().fa_oracle_forward_causal_rows if causal else lib().fa_oracle_forward_rows
+    fn(_f(q), _f(k), _f(v), _f(o), bh, n, d, float(scale), accum, nthreads, b0, b1, r0, r1)
     return o
 
 

@@ -300,3 +300,62 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     for algo in (0, 5, 6, 9, 11, 12):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
         _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol)
+
+
+# ---- causal variant (not a reference entry point) --------------------------------
+def _run_causal(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False):
+    q, k, v = (_to_dev(torch, x, fmt) for x in (qb, kb, vb))
+    od = _tdtype(torch, fmt) if out_same else torch.float32
+    o = fa.fa_forward(q, k, v, out_dtype=od, algo=algo, causal=True)
+    torch.cuda.synchronize()
+    return o.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_causal_vs_oracle(fa, oracle, torch_cuda, fmt):
+    """Every kernel that implements the mask, ragged N around the 32/64/256-row block edges."""
+    for d in (16, 64, 128):
+        for n in (1, 17, 64, 65, 255, 256, 257, 600):
+            (q, k, v), (qb, kb, vb) = oracle.make_qkv(3, n, d, fmt=fmt, seed=900 + n + d)
+            want = oracle.forward(q, k, v, causal=True, nthreads=8)
+            for algo in ((0, 1, 2) if d in (64, 128) else (0, 1)):
+                got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt, algo=algo)
+                _check(oracle, got, want, fmt, f"causal d={d} n={n} algo={algo} fmt={fmt}")
+            got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt, out_same=True)
+            _check(oracle, got, want, fmt, f"causal d={d} n={n} out=same", out_same=True)
+
+
+def test_causal_prefix_identity(fa, oracle, torch_cuda):
+    """Row i of the causal forward == row i of the plain forward over the first i+1 keys, and the
+    first row is exactly V[0]: properties that do not need the oracle."""
+    n, d = 384, 64
+    (q, k, v), (qb, kb, vb) = oracle.make_qkv(2, n, d, fmt=0, seed=77)
+    got = _run_causal(fa, torch_cuda, qb, kb, vb, 0)
+    np.testing.assert_allclose(got[:, 0], v[:, 0], atol=1e-6)
+    for i in (1, 63, 64, 200, 383):
+        plain = _run(fa, torch_cuda, qb[:, :i + 1], kb[:, :i + 1], vb[:, :i + 1], 0, algo=2)
+        assert np.abs(got[:, i] - plain[:, i]).max() <= 2e-3, i
+
+
+def test_causal_future_keys_do_not_matter(fa, oracle, torch_cuda):
+    """Changing K/V rows j > i must not change output rows <= i, bit for bit."""
+    n, d = 300, 128
+    (_, _, _), (qb, kb, vb) = oracle.make_qkv(2, n, d, fmt=1, seed=5)
+    a = _run_causal(fa, torch_cuda, qb, kb, vb, 1)
+    kb2, vb2 = kb.copy(), vb.copy()
+    kb2[:, 150:] = kb[:, 150:][:, ::-1]
+    vb2[:, 150:] = 0x7BFF   # large finite bf16
+    b = _run_causal(fa, torch_cuda, qb, kb2, vb2, 1)
+    assert np.array_equal(a[:, :150], b[:, :150])
+
+
+def test_causal_big(fa, oracle, torch_cuda):
+    """B8 H16 N4096 d64 causal: sampled rows against the oracle."""
+    fmt, bh, n, d = 0, 128, 4096, 64
+    (q, k, v), (qb, kb, vb) = oracle.make_qkv(bh, n, d, fmt=fmt, seed=42)
+    got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt)
+    assert np.isfinite(got).all()
+    for b, r0 in ((0, 0), (17, 1000), (127, 4032)):
+        want = oracle.forward(q, k, v, causal=True, nthreads=8, bh_range=(b, b + 1), row_range=(r0, r0 + 64))
+        ma = np.abs(got[b, r0:r0 + 64] - want[b, r0:r0 + 64]).max()
+        assert ma <= MAX_ABS, (b, r0, ma)

@@ -54,6 +54,23 @@ def test_oracle_rows_subset_and_threads(oracle):
     assert not part[0].any() and not part[1:3, :10].any() and not part[1:3, 40:].any()
 
 
+def test_causal_oracle_is_prefix_of_plain_oracle(oracle):
+    """The causal oracle is not a reference function; it is pinned through this identity with the
+    pinned plain oracle: row i over keys 0..i, and an explicit numpy masked softmax."""
+    (q, k, v), _ = oracle.make_qkv(2, 45, 32, seed=3)
+    c = oracle.forward(q, k, v, causal=True)
+    for i in (0, 1, 17, 44):
+        p = oracle.forward(q[:, :i + 1], k[:, :i + 1], v[:, :i + 1])
+        assert np.array_equal(c[:, i], p[:, i])
+    s = np.einsum("bid,bjd->bij", q.astype(np.float64), k.astype(np.float64)) / np.sqrt(32.0)
+    s = np.where(np.tril(np.ones((45, 45), bool)), s, -np.inf)
+    w = np.exp(s - s.max(-1, keepdims=True))
+    want = np.einsum("bij,bjd->bid", w / w.sum(-1, keepdims=True), v.astype(np.float64))
+    assert np.abs(c - want).max() < 2e-6
+    assert np.array_equal(oracle.forward(q, k, v, causal=True, accum=1, nthreads=4, row_range=(10, 20))[:, 10:20],
+                          oracle.forward(q, k, v, causal=True, accum=1)[:, 10:20])
+
+
 def test_oracle_scale_argument(oracle):
     (q, k, v), _ = oracle.make_qkv(1, 40, 16, oracle.F16, seed=6)
     a = oracle.forward(q, k, v, scale=0.5)

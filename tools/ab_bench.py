@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--out", default="f32")
+    ap.add_argument("--causal", action="store_true", help="fa_forward_causal (algos 0,1,2); FLOPs counted as 4*BH*d*N(N+1)/2")
     args = ap.parse_args()
     import torch
     import flashattention_kernel_project_amd as fa
@@ -36,7 +37,7 @@ def main():
     outs = {a: torch.empty(q.shape, device="cuda", dtype=odt) for a in algos}
     for a in algos:
         for _ in range(3):
-            fa.fa_forward(q, k, v, out=outs[a], algo=a)
+            fa.fa_forward(q, k, v, out=outs[a], algo=a, causal=args.causal)
     torch.cuda.synchronize()
     times = {a: [] for a in algos}
     for _ in range(args.rounds):
@@ -44,11 +45,13 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
-                fa.fa_forward(q, k, v, out=outs[a], algo=a)
+                fa.fa_forward(q, k, v, out=outs[a], algo=a, causal=args.causal)
             e1.record()
             torch.cuda.synchronize()
             times[a].append(e0.elapsed_time(e1) / args.iters)
     fl = fa.attention_flops(args.B * args.H, args.N, args.d)
+    if args.causal:
+        fl *= (args.N + 1) / (2.0 * args.N)
     base = outs[algos[0]].float()
     for a in algos:
         med, mn = statistics.median(times[a]), min(times[a])
