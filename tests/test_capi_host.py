@@ -81,3 +81,19 @@ def test_shard_range(fa):
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         fa.shard_range(8, 8, 8)
+
+
+def test_torch_custom_op_registers(fa):
+    """torch.ops.fa_mi355.forward exists after register(), traces on meta tensors, and has no CPU kernel."""
+    import pytest
+    import torch
+    from flashattention_kernel_project_amd.torch_op import register
+    register()
+    register()
+    q = torch.empty(2, 3, 50, 64, dtype=torch.float16, device="meta")
+    o = torch.ops.fa_mi355.forward(q, q, q, 0.125, False, True)
+    assert o.shape == q.shape and o.dtype == torch.float32
+    assert torch.ops.fa_mi355.forward(q, q, q, 0.125, True, False).dtype == torch.float16
+    with pytest.raises(Exception):   # no CPU implementation: the product path is the HIP library only
+        c = torch.zeros(1, 1, 16, 64, dtype=torch.float16)
+        torch.ops.fa_mi355.forward(c, c, c, 0.125, False, True)

@@ -359,3 +359,50 @@ def test_causal_big(fa, oracle, torch_cuda):
         want = oracle.forward(q, k, v, causal=True, nthreads=8, bh_range=(b, b + 1), row_range=(r0, r0 + 64))
         ma = np.abs(got[b, r0:r0 + 64] - want[b, r0:r0 + 64]).max()
         assert ma <= MAX_ABS, (b, r0, ma)
+
+
+# ---- second, independent oracle on the GPU box: PyTorch's own attention ----------
+def _sdpa_fp32(torch, q, k, v, causal):
+    """Plain fp32 softmax(QK^T/sqrt(d))V in torch ops, one head at a time (no fused kernel involved)."""
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    n, d = q.shape[-2:]
+    mask = torch.ones(n, n, dtype=torch.bool, device=q.device).tril_() if causal else None
+    for b in range(q.shape[0]):
+        for h in range(q.shape[1]):
+            s = (q[b, h].float() @ k[b, h].float().T) * (1.0 / d ** 0.5)
+            if causal:
+                s = s.masked_fill(~mask, float("-inf"))
+            out[b, h] = torch.softmax(s, dim=-1) @ v[b, h].float()
+    return out
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_full_size_against_torch_fp32(fa, torch_cuda, fmt, causal):
+    """ALL rows of B8 H16 N4096 d64 (BASELINE's metric config) against fp32 torch ops on the GPU,
+    through the registered custom op."""
+    torch = torch_cuda
+    from flashattention_kernel_project_amd.torch_op import register
+    register()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q, k, v = (torch.randn(8, 16, 4096, 64, generator=g, device="cuda").to(_tdtype(torch, fmt)) for _ in range(3))
+    got = torch.ops.fa_mi355.forward(q, k, v, 0.125, causal, True)
+    want = _sdpa_fp32(torch, q, k, v, causal)
+    torch.cuda.synchronize()
+    err = (got - want).abs().max().item()
+    assert err <= MAX_ABS and torch.isfinite(got).all(), err
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel <= REL_L2[fmt], rel
+
+
+def test_sdpa_like_matches_torch_sdpa(fa, torch_cuda):
+    """Drop-in call shape of F.scaled_dot_product_attention, 16-bit output, d=128."""
+    torch = torch_cuda
+    from flashattention_kernel_project_amd.torch_op import sdpa_like
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q, k, v = (torch.randn(2, 4, 1000, 128, generator=g, device="cuda").half() for _ in range(3))
+    for causal in (False, True):
+        got = sdpa_like(q, k, v, is_causal=causal)
+        want = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float(), is_causal=causal)
+        assert got.dtype == torch.float16
+        assert (got.float() - want).abs().max().item() <= MAX_ABS
