@@ -34,20 +34,22 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define FA_W64_WAVES 8
 #endif
 constexpr int kW = FA_W64_WAVES;   // waves per workgroup (4: two independent 256-row workgroups per CU)
-constexpr int kRows = 64 * kW;     // query rows per workgroup
-constexpr int kLoads = 512 / (64 * kW);   // 16-B K (and V) chunks per thread and tile
 constexpr int kAhead = 2, kRing = kAhead + 1;   // LDS fragment read-ahead
 }  // namespace w64
 
-template <typename T, bool kOutF32>
+// D = head dim (64 or 128); X = 32-row query blocks per wave (2 at D = 64; 1 at D = 128, where the
+// 128-wide O^T leaves no room for a second block -- that instantiation is the plain tiled kernel plus
+// the optimistic pass, packed fma, fragment read-ahead and persistent grid).
+template <typename T, int D, int X, bool kOutF32>
 __global__ __launch_bounds__(64 * w64::kW, 2)
 void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                        const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                        int N, int nqb, float scale_log2e, unsigned total_wg)
 {
     using namespace w64;
-    constexpr int D = 64;
     using G = TileGeom<D>;
+    constexpr int kRows = 32 * X * kW;                              // query rows per workgroup
+    constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);      // 16-B K (and V) chunks per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][K tile][V tile]
 
     const unsigned tid  = threadIdx.x;
@@ -97,11 +99,11 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
-    const unsigned q_row0 = qb * kRows + wave * 64u + r;   // row of query block 0; block 1 is 32 rows further
+    const unsigned q_row0 = qb * kRows + wave * (32u * X) + r;   // row of query block 0; block x is 32x rows further
 
-    u32x4 qf[2][G::kKSteps];
+    u32x4 qf[X][G::kKSteps];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < X; ++x)
 #pragma unroll
         for (int s = 0; s < G::kKSteps; ++s) {
             u32x4 raw = buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
@@ -110,14 +112,14 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             qf[x][s] = raw;
         }
 
-    f32x16 o[2][G::kDBlocks];
-    float m_ref[2] = {0.0f, 0.0f}, l_part[2] = {0.0f, 0.0f};
+    f32x16 o[X][G::kDBlocks];
+    float m_ref[X] = {}, l_part[X] = {};
     u32x4 kst[kLoads], vst[kLoads];
 
     auto run = [&](auto track_c) __attribute__((always_inline)) {
         constexpr bool kTrack = decltype(track_c)::value;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < X; ++x) {
 #pragma unroll
             for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
             l_part[x] = 0.0f;
@@ -144,7 +146,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             }
 
             // ---- S^T = K.Q^T for both query blocks: each K fragment feeds two MFMAs ------------
-            f32x16 s[2][2];
+            f32x16 s[X][2];
             u32x4 frag[kRing];
             auto read_k = [&](auto fc) {
                 constexpr int f = decltype(fc)::value;
@@ -157,14 +159,14 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             sfor<kAhead>([&](auto fc) { read_k(fc); });
             sfor<2 * G::kKSteps>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, kb = f / G::kKSteps, ks = f % G::kKSteps;
-                s[0][kb] = T::mfma32(frag[f % kRing], qf[0][ks], ks == 0 ? zero16 : s[0][kb]);
-                s[1][kb] = T::mfma32(frag[f % kRing], qf[1][ks], ks == 0 ? zero16 : s[1][kb]);
+#pragma unroll
+                for (int x = 0; x < X; ++x) s[x][kb] = T::mfma32(frag[f % kRing], qf[x][ks], ks == 0 ? zero16 : s[x][kb]);
                 read_k(std::integral_constant<int, f + kAhead>{});
             });
 
             if (partial && t + 1 == ntiles) {   // keys >= N -> -inf (p = 0)
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+                for (int x = 0; x < X; ++x)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -177,7 +179,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             // ---- reference max: tile 0 always; later tiles only in the tracked (fallback) pass ----
             if (kTrack || t == 0) {
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
+                for (int x = 0; x < X; ++x) {
                     float tmax = -INFINITY;
 #pragma unroll
                     for (int e = 0; e < 32; e += 2) tmax = max3(tmax, s[x][e >> 4][e & 15], s[x][(e + 1) >> 4][(e + 1) & 15]);
@@ -198,10 +200,10 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             }
 
             // ---- P = 2^(c*S - m), row sums (fp32), packed to 16 bit ----------------------------------
-            u32x4 pk[2][4];
+            u32x4 pk[X][4];
             const f32x2 c2 = {c, c};
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int x = 0; x < X; ++x) {
                 const f32x2 nm = {-m_ref[x], -m_ref[x]};
                 float ls0 = 0.0f, ls1 = 0.0f;
 #pragma unroll
@@ -239,15 +241,15 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             sfor<kAhead>([&](auto fc) { read_v(fc); });
             sfor<4 * G::kDBlocks>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, db = f / 4, ks = f % 4;
-                if constexpr (f == 2 * G::kDBlocks) {   // land the next tile in the other buffer
+                if constexpr (f == 2 * G::kDBlocks) {   // land the next tile in the other buffer (half way through PV)
 #pragma unroll
                     for (int p = 0; p < kLoads; ++p) {
                         lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds[p], kst[p]);
                         lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds[p], vst[p]);
                     }
                 }
-                o[0][db] = T::mfma32(frag[f % kRing], pk[0][ks], o[0][db]);
-                o[1][db] = T::mfma32(frag[f % kRing], pk[1][ks], o[1][db]);
+#pragma unroll
+                for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(frag[f % kRing], pk[x][ks], o[x][db]);
                 read_v(std::integral_constant<int, f + kAhead>{});
             });
             __syncthreads();
@@ -255,23 +257,26 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     };
 
     run(no);
-    float l_row[2] = {l_part[0] + swap_halves(l_part[0]), l_part[1] + swap_halves(l_part[1])};
-    {
-        // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
-        const float lim = T::id == 1 ? INFINITY : 60000.0f;
-        const bool bad = !(l_row[0] < lim) || !(l_row[1] < lim);
-        if (__syncthreads_or(bad ? 1 : 0)) {
-            run(yes);
-            l_row[0] = l_part[0] + swap_halves(l_part[0]);
-            l_row[1] = l_part[1] + swap_halves(l_part[1]);
-        }
+    float l_row[X];
+    bool bad = false;
+    // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
+    const float lim = T::id == 1 ? INFINITY : 60000.0f;
+#pragma unroll
+    for (int x = 0; x < X; ++x) {
+        l_row[x] = l_part[x] + swap_halves(l_part[x]);
+        bad = bad || !(l_row[x] < lim);
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+        run(yes);
+#pragma unroll
+        for (int x = 0; x < X; ++x) l_row[x] = l_part[x] + swap_halves(l_part[x]);
     }
 
     constexpr unsigned es = kOutF32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t ro =
         make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < X; ++x) {
         const float inv = 1.0f / l_row[x];
         const unsigned row = q_row0 + 32u * x;
 #pragma unroll
@@ -293,12 +298,13 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     }   // persistent loop over work items
 }
 
-template <typename T, bool kOutF32>
+template <typename T, int D, int X, bool kOutF32>
 static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* O,
                              int BH, int N, float scale, hipStream_t stream)
 {
-    using G = TileGeom<64>;
-    const int nqb = (N + w64::kRows - 1) / w64::kRows;
+    using G = TileGeom<D>;
+    constexpr int kRows = 32 * X * w64::kW;
+    const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     static const int grid_cap = [] {
@@ -308,7 +314,10 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
     }();
     const long long cap = (long long)grid_cap * (8 / w64::kW);
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();
@@ -318,13 +327,20 @@ hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                         hipStream_t stream)
 {
-    if (D != 64) return hipErrorInvalidValue;
-    if ((unsigned long long)(N + w64::kRows) * 64ull * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * w64::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D == 64) {
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_w64<F16, 64, 2, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64<F16, 64, 2, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64<BF16, 64, 2, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<BF16, 64, 2, false>(Q, K, V, O, BH, N, scale, stream);
+    }
     if (in_dtype == 0)
-        return out_dtype == 0 ? launch_w64<F16, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64<F16, false>(Q, K, V, O, BH, N, scale, stream);
-    return out_dtype == 0 ? launch_w64<BF16, true>(Q, K, V, O, BH, N, scale, stream)
-                          : launch_w64<BF16, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64<F16, 128, 1, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<F16, 128, 1, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_w64<BF16, 128, 1, true>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_w64<BF16, 128, 1, false>(Q, K, V, O, BH, N, scale, stream);
 }
 
 }  // namespace fa
