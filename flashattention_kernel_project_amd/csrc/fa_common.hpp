@@ -49,6 +49,12 @@ struct F16 {
         return (float)__builtin_bit_cast(_Float16, b);
     }
     static constexpr unsigned kOnes2 = 0x3C003C00u;   // two 1.0 halves
+    // Row sums: fp32 v_add of the un-rounded p (rounding P to fp16 perturbs a weight by 2^-11: far
+    // inside the tolerance, and v_add is cheaper than v_dot2c at the power cap).
+#ifndef FA_F16_SUM_ROUNDED
+#define FA_F16_SUM_ROUNDED 0
+#endif
+    static constexpr bool kSumRounded = FA_F16_SUM_ROUNDED != 0;
     // acc + lo(w) + hi(w) in fp32: one v_dot2c_f32_f16 against (1, 1)
     static __device__ __forceinline__ float sum2(unsigned w, float acc) {
         return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, w), __builtin_bit_cast(f16x2, kOnes2), acc, false);
@@ -73,6 +79,10 @@ struct BF16 {
     static __device__ __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
     static __device__ __forceinline__ float one(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
     static constexpr unsigned kOnes2 = 0x3F803F80u;   // two 1.0 bfloat16
+    // Row sums over the ROUNDED p (one v_dot2c per packed pair): O = sum(p'v)/sum(p') keeps the
+    // weights a convex combination, so a row dominated by one key returns that V row exactly instead
+    // of V(1 + 2^-9); with un-rounded sums a peaked row can miss the 1e-2 bar at |V| ~ 4.
+    static constexpr bool kSumRounded = true;
     static __device__ __forceinline__ float sum2(unsigned w, float acc) {   // v_dot2c_f32_bf16
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), __builtin_bit_cast(bf16x2, kOnes2), acc, false);
     }

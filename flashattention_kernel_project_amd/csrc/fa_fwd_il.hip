@@ -336,8 +336,13 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             constexpr int j = decltype(jc)::value, e0 = 2 * j, e1 = e0 + 1;
             pk_cur[j >> 2][j & 3] = T::pack2(s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]);
             if constexpr (!FA_IL_MFMA_SUM) {
-                ls0 += s_cur[e0 >> 4][e0 & 15];
-                ls1 += s_cur[e1 >> 4][e1 & 15];
+                if constexpr (T::kSumRounded) {
+                    if constexpr ((j & 1) == 0) ls0 = T::sum2(pk_cur[j >> 2][j & 3], ls0);
+                    else ls1 = T::sum2(pk_cur[j >> 2][j & 3], ls1);
+                } else {
+                    ls0 += s_cur[e0 >> 4][e0 & 15];
+                    ls1 += s_cur[e1 >> 4][e1 & 15];
+                }
             }
         };
         // The max chains read S(t+1) inside the slot sequence only when every QK^T MFMA has been

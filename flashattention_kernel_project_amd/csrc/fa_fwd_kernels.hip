@@ -214,16 +214,23 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kb][i] = fast_exp2(__builtin_fmaf(s[kb][i], c, neg_m));
+            if constexpr (!T::kSumRounded) {
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                lsum0 += s[kb][i];
-                lsum1 += s[kb][i + 1];
+                for (int i = 0; i < 16; i += 2) {
+                    lsum0 += s[kb][i];
+                    lsum1 += s[kb][i + 1];
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
+                for (int w = 0; w < 4; ++w) {
                     pk[kb * 2 + s2][w] = T::pack2(s[kb][8 * s2 + 2 * w], s[kb][8 * s2 + 2 * w + 1]);
+                    if constexpr (T::kSumRounded) {
+                        if (w & 1) lsum1 = T::sum2(pk[kb * 2 + s2][w], lsum1);
+                        else lsum0 = T::sum2(pk[kb * 2 + s2][w], lsum0);
+                    }
+                }
         }
         l_part += lsum0 + lsum1;
 
@@ -486,11 +493,16 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     if (algo == 0 && D == 64) {
-        // d = 64: the interleaved kernel.  256-row workgroups (one per CU) when they fill the chip at
-        // least twice over, else 128-row workgroups (two per CU) for twice the parallelism.
+        // d = 64: 64 query rows per wave in 512-row workgroups (fa_fwd_w64.hip) when those fill the chip
+        // at least twice over; else the interleaved kernel with 256-row workgroups, or 128-row ones
+        // (two per CU) for twice the parallelism.
+        const long long nwg512 = (long long)BH * ((N + 511) / 512);
+        if (nwg512 >= 512) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, nwg256 >= 512 ? 8 : 4, stream);
     }
+    // d = 128: the tiled stream with the optimistic pass, packed fma and a persistent grid (fa_fwd_w64.hip, X = 1)
+    if (algo == 0 && D == 128) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 7 || algo == 8) {   // experimental occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out

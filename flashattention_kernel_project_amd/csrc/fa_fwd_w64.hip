@@ -30,6 +30,10 @@ template <int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
+#ifndef FA_W64_DOT2
+#define FA_W64_DOT2 1   // row sums over the ROUNDED p, one v_dot2c per packed pair (bf16: needed for accuracy, fa_common.hpp;
+                        // fp16: -1.1 % wall in THIS kernel's separate softmax phase, +2.6 % in the interleaved kernel)
+#endif
 #ifndef FA_W64_WAVES
 #define FA_W64_WAVES 8
 #endif
@@ -215,8 +219,13 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
                         v = __builtin_elementwise_fma(v, c2, nm);
                         const float p0 = fast_exp2(v[0]), p1 = fast_exp2(v[1]);
                         pk[x][q4][w] = T::pack2(p0, p1);
-                        ls0 += p0;
-                        ls1 += p1;
+                        if constexpr (T::kSumRounded || FA_W64_DOT2) {
+                            if (w & 1) ls1 = T::sum2(pk[x][q4][w], ls1);
+                            else ls0 = T::sum2(pk[x][q4][w], ls0);
+                        } else {
+                            ls0 += p0;
+                            ls1 += p1;
+                        }
                     }
                 }
                 l_part[x] += ls0 + ls1;

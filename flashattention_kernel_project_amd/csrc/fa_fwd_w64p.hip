@@ -48,7 +48,7 @@ constexpr int kRing = 4;           // fragment registers (8 fragments per step: 
 #define FA_W64P_SETPRIO 0
 #endif
 #ifndef FA_W64P_DOT2
-#define FA_W64P_DOT2 0             // row sums: one v_dot2c per packed pair (sum of the ROUNDED p, the values PV uses) instead of two v_add
+#define FA_W64P_DOT2 T::kSumRounded             // row sums of the ROUNDED p by v_dot2c: bf16 only (fa_common.hpp; +1.8 % wall when forced on for fp16)
 #endif
 #ifndef FA_W64P_STAGE_SLOT
 #define FA_W64P_STAGE_SLOT 8       // MFMA slot of the second step in front of which tile j+2 is written to LDS

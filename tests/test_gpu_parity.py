@@ -285,21 +285,23 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
     qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
     want = oracle.forward(q, k, v, accum=1, nthreads=8)
-    # A one-hot row reproduces |V| times the rounding error of its single packed weight (the row sum is
-    # taken from the unrounded fp32 p, as in the reference's fp32 statistics): 2^-9 for bf16, |V| <= ~4.5.
-    tol = MAX_ABS * (2.0 if fmt == 1 else 1.0)
-    for algo in (0, 5, 6, 9, 11, 12):
+    # A one-hot row reproduces |V| times the rounding error of its single packed weight when the row sum
+    # is taken from the unrounded fp32 p: 2^-9 for bf16, |V| <= ~4.5.  The shipped kernels (AUTO, 5, 6,
+    # 13, 14) sum the ROUNDED bf16 weights instead and meet the plain bar; the A/B variants do not.
+    def tol(algo):
+        return MAX_ABS * (2.0 if fmt == 1 and algo in (9, 11, 12) else 1.0)
+    for algo in (0, 5, 6, 9, 11, 12, 13, 14):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
-        _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol)
+        _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol(algo))
     # ragged N with the overflow in the partial last tile
     n2 = 333
     (q2, k2, v2), _ = oracle.make_qkv(1, n2, d, fmt, seed=9)
     k2[0, n2 - 1] = q2[0, 200] * 40.0
     q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
     want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
-    for algo in (0, 5, 6, 9, 11, 12):
+    for algo in (0, 5, 6, 9, 11, 12, 13, 14):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
-        _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol)
+        _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol(algo))
 
 
 # ---- causal variant (not a reference entry point) --------------------------------
