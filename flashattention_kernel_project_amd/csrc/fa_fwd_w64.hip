@@ -38,7 +38,13 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define FA_W64_WAVES 8
 #endif
 constexpr int kW = FA_W64_WAVES;   // waves per workgroup (4: two independent 256-row workgroups per CU)
-constexpr int kAhead = 2, kRing = kAhead + 1;   // LDS fragment read-ahead
+#ifndef FA_W64_AHEAD
+#define FA_W64_AHEAD 2
+#endif
+#ifndef FA_W64_STAGE_AT
+#define FA_W64_STAGE_AT 2   // the staged tile is written to LDS in front of PV fragment FA_W64_STAGE_AT * kDBlocks
+#endif
+constexpr int kAhead = FA_W64_AHEAD, kRing = kAhead + 1;   // LDS fragment read-ahead
 }  // namespace w64
 
 // D = head dim (64 or 128); X = 32-row query blocks per wave (2 at D = 64; 1 at D = 128, where the
@@ -250,7 +256,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             sfor<kAhead>([&](auto fc) { read_v(fc); });
             sfor<4 * G::kDBlocks>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, db = f / 4, ks = f % 4;
-                if constexpr (f == 2 * G::kDBlocks) {   // land the next tile in the other buffer (half way through PV)
+                if constexpr (f == FA_W64_STAGE_AT * G::kDBlocks) {   // land the next tile in the other buffer (half way through PV)
 #pragma unroll
                     for (int p = 0; p < kLoads; ++p) {
                         lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds[p], kst[p]);
