@@ -44,13 +44,17 @@ constexpr int kW = FA_W64_WAVES;   // waves per workgroup (4: two independent 25
 #ifndef FA_W64_STAGE_AT
 #define FA_W64_STAGE_AT 2   // the staged tile is written to LDS in front of PV fragment FA_W64_STAGE_AT * kDBlocks
 #endif
-constexpr int kAhead = FA_W64_AHEAD, kRing = kAhead + 1;   // LDS fragment read-ahead
+constexpr int kAhead = FA_W64_AHEAD;   // LDS fragment read-ahead
 }  // namespace w64
 
 // D = head dim (64 or 128); X = 32-row query blocks per wave (2 at D = 64; 1 at D = 128, where the
 // 128-wide O^T leaves no room for a second block -- that instantiation is the plain tiled kernel plus
 // the optimistic pass, packed fma, fragment read-ahead and persistent grid).
-template <typename T, int D, int X, bool kOutF32>
+// kCausal: query row i attends to keys 0..i.  The workgroup stops at the tile that holds its last row's
+// diagonal, a wave skips (but still stages and synchronises) tiles wholly above its rows, crossed
+// tiles get the element mask.  Launched one workgroup per item, query blocks last-to-first within a
+// head, so the hardware dispatcher balances the unequal items.
+template <typename T, int D, int X, bool kOutF32, bool kCausal = false>
 __global__ __launch_bounds__(64 * w64::kW, 2)
 void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                        const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -58,6 +62,8 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
 {
     using namespace w64;
     using G = TileGeom<D>;
+    // the causal d=64 instantiation is 12 VGPRs over budget with the 3-deep fragment ring: read one ahead there
+    constexpr int kAhead = (kCausal && X == 2) ? 1 : w64::kAhead, kRing = kAhead + 1;
     constexpr int kRows = 32 * X * kW;                              // query rows per workgroup
     constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);      // 16-B K (and V) chunks per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][K tile][V tile]
@@ -103,13 +109,16 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
     const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const unsigned bh = wgid / (unsigned)nqb;
-    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const unsigned qb = kCausal ? (unsigned)nqb - 1u - (wgid - bh * (unsigned)nqb) : wgid - bh * (unsigned)nqb;
     const size_t head_elems = (size_t)N * D;
     const unsigned head_bytes = (unsigned)(head_elems * 2);
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
-    const unsigned q_row0 = qb * kRows + wave * (32u * X) + r;   // row of query block 0; block x is 32x rows further
+    const unsigned wave_row0 = qb * kRows + wave * (32u * X);    // first query row of this wave
+    const unsigned q_row0 = wave_row0 + r;   // row of query block 0; block x is 32x rows further
+    int ntiles_wg = ntiles;
+    if constexpr (kCausal) ntiles_wg = min(ntiles, (int)(min((unsigned)N - 1u, qb * kRows + kRows - 1u) / kBlockN) + 1);
 
     u32x4 qf[X][G::kKSteps];
 #pragma unroll
@@ -146,13 +155,24 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
         }
         __syncthreads();
 
-        for (int t = 0; t < ntiles; ++t) {
+        for (int t = 0; t < ntiles_wg; ++t) {
             const unsigned cur = (unsigned)t & 1u;
             // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
                 kst[p] = buf_load16(rk, (unsigned)(t + 1) * G::kTileBytes + st_goff[p]);
                 vst[p] = buf_load16(rv, (unsigned)(t + 1) * G::kTileBytes + st_goff[p]);
+            }
+
+            // causal: tiles wholly above this wave's rows contribute nothing (wave-uniform; tile 0 never is)
+            if (kCausal && (unsigned)(t * kBlockN) > wave_row0 + 32u * X - 1u) {
+#pragma unroll
+                for (int p = 0; p < kLoads; ++p) {
+                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds[p], kst[p]);
+                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds[p], vst[p]);
+                }
+                __syncthreads();
+                continue;
             }
 
             // ---- S^T = K.Q^T for both query blocks: each K fragment feeds two MFMAs ------------
@@ -184,6 +204,20 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
                             const int key = t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
                             if (key >= N) s[x][kb][i] = -INFINITY;
                         }
+            }
+
+            if constexpr (kCausal) {   // tiles the diagonal crosses: keys after the query -> -inf
+                if ((unsigned)(t * kBlockN) + (unsigned)kBlockN - 1u > wave_row0) {
+#pragma unroll
+                    for (int x = 0; x < X; ++x)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const unsigned key = (unsigned)(t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2)) + 4u * h;
+                                if (key > q_row0 + 32u * x) s[x][kb][i] = -INFINITY;
+                            }
+                }
             }
 
             // ---- reference max: tile 0 always; later tiles only in the tracked (fallback) pass ----
@@ -313,7 +347,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     }   // persistent loop over work items
 }
 
-template <typename T, int D, int X, bool kOutF32>
+template <typename T, int D, int X, bool kOutF32, bool kCausal = false>
 static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* O,
                              int BH, int N, float scale, hipStream_t stream)
 {
@@ -328,34 +362,49 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
         return cus;
     }();
     const long long cap = (long long)grid_cap * (8 / w64::kW);
-    const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32>),
+    const unsigned grid = (nwg > cap && !kCausal) ? (unsigned)cap : (unsigned)nwg;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
+    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();
+}
+
+template <bool kCausal>
+static hipError_t w64_dispatch_impl(const void* Q, const void* K, const void* V, void* O,
+                                    int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                                    hipStream_t stream)
+{
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * w64::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D == 64) {
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_w64<F16, 64, 2, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64<F16, 64, 2, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64<BF16, 64, 2, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<BF16, 64, 2, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
+    }
+    if (in_dtype == 0)
+        return out_dtype == 0 ? launch_w64<F16, 128, 1, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<F16, 128, 1, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_w64<BF16, 128, 1, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_w64<BF16, 128, 1, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
 }
 
 hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                         hipStream_t stream)
 {
-    if (D != 64 && D != 128) return hipErrorInvalidValue;
-    if ((unsigned long long)(N + 64 * w64::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
-    if (D == 64) {
-        if (in_dtype == 0)
-            return out_dtype == 0 ? launch_w64<F16, 64, 2, true>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_w64<F16, 64, 2, false>(Q, K, V, O, BH, N, scale, stream);
-        return out_dtype == 0 ? launch_w64<BF16, 64, 2, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64<BF16, 64, 2, false>(Q, K, V, O, BH, N, scale, stream);
-    }
-    if (in_dtype == 0)
-        return out_dtype == 0 ? launch_w64<F16, 128, 1, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64<F16, 128, 1, false>(Q, K, V, O, BH, N, scale, stream);
-    return out_dtype == 0 ? launch_w64<BF16, 128, 1, true>(Q, K, V, O, BH, N, scale, stream)
-                          : launch_w64<BF16, 128, 1, false>(Q, K, V, O, BH, N, scale, stream);
+    return w64_dispatch_impl<false>(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+}
+
+hipError_t w64_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
+                               int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                               hipStream_t stream)
+{
+    return w64_dispatch_impl<true>(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
 }
 
 }  // namespace fa
