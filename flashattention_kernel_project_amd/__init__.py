@@ -10,6 +10,8 @@ or fails to load, every op raises.
 from .capi import build, lib, version, FaError  # noqa: F401
 from .ops import (  # noqa: F401
     fa_forward,
+    fa_forward_splitkv,
+    splitkv_workspace_bytes,
     flashattn_forward_wmma,
     flashattn_streaming_16x16_mw,
     flashattn_streaming_16x16_mw_kt,
@@ -20,7 +22,7 @@ from .shard import shard_range  # noqa: F401
 
 __all__ = [
     "build", "lib", "version", "FaError",
-    "fa_forward", "flashattn_forward_wmma",
+    "fa_forward", "fa_forward_splitkv", "splitkv_workspace_bytes", "flashattn_forward_wmma",
     "flashattn_streaming_16x16_mw", "flashattn_streaming_16x16_mw_kt",
     "attention_flops", "attention_min_bytes", "shard_range",
 ]

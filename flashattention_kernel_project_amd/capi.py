@@ -20,6 +20,8 @@ SYMBOLS = (
     "fa_forward",
     "fa_forward_ex",
     "fa_forward_causal",
+    "fa_forward_splitkv_workspace_bytes",
+    "fa_forward_splitkv",
     "flashattn_streaming_16x16_mw",
     "flashattn_streaming_16x16_mw_kt",
     "fa_mi355_version",
@@ -75,10 +77,13 @@ def lib() -> C.CDLL:
         L.fa_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, vp]
         L.fa_forward_ex.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, i, vp]
         L.fa_forward_causal.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, i, vp]
+        L.fa_forward_splitkv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i, i, vp, C.c_size_t, vp]
+        L.fa_forward_splitkv_workspace_bytes.argtypes = [i, i, i, i, i]
         L.flashattn_streaming_16x16_mw.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         L.flashattn_streaming_16x16_mw_kt.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         for s in SYMBOLS[:-1]:
             getattr(L, s).restype = C.c_int
+        L.fa_forward_splitkv_workspace_bytes.restype = C.c_size_t
         L.fa_mi355_version.argtypes = []
         L.fa_mi355_version.restype = C.c_char_p
         _lib = L

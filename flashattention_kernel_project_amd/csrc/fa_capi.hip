@@ -9,6 +9,9 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
 hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
                                    int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                                    int algo, hipStream_t stream);
+hipError_t split_dispatch(const void* Q, const void* K, const void* V, void* O, void* ws, size_t ws_bytes,
+                          int BH, int Nq, int Nk, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream);
+size_t split_workspace_bytes(int BH, int Nq, int Nk, int D);
 hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
                                 int num_batches, int seq_len, float scale, bool k_transposed,
                                 hipStream_t stream);
@@ -67,6 +70,21 @@ int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
     if (out_dtype != FA_OUT_F32 && out_dtype != FA_OUT_SAME) return (int)hipErrorInvalidValue;
     return (int)fa::forward_causal_dispatch(Q, K, V, O, B * H, N, d, scale, in_dtype, out_dtype, algo,
                                             static_cast<hipStream_t>(stream));
+}
+
+size_t fa_forward_splitkv_workspace_bytes(int B, int H, int Nq, int Nk, int d)
+{
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || (long long)B * H > 0x7FFFFFFFll) return 0;
+    return fa::split_workspace_bytes(B * H, Nq, Nk, d);
+}
+
+int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
+                       int B, int H, int Nq, int Nk, int d, float scale,
+                       int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
+    return (int)fa::split_dispatch(Q, K, V, O, workspace, workspace_bytes, B * H, Nq, Nk, d, scale, in_dtype, out_dtype,
+                                   static_cast<hipStream_t>(stream));
 }
 
 int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,

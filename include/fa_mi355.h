@@ -71,6 +71,19 @@ int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                       int B, int H, int N, int d, float scale,
                       int in_dtype, int out_dtype, int algo, void* stream);
 
+/* Nq != Nk with a split over the keys ("flash-decoding"): Q [B*H,Nq,d], K,V [B*H,Nk,d], O [B*H,Nq,d],
+ * no mask, d in {64,128}.  Meant for few query rows against a long K/V, where one workgroup per
+ * (head, query block) cannot fill the chip: the keys are cut into S chunks (S chosen by the library
+ * from B*H, Nq, Nk), each chunk leaves an unnormalised partial result in `workspace`, and a second
+ * small kernel merges them.  The caller owns the workspace (size from
+ * fa_forward_splitkv_workspace_bytes(); 0 means S = 1 and `workspace` may be NULL).
+ * NOT a reference entry point (cf. the single-query experiment
+ * flashattn_warp_spc_2/flashattn_streaming_16x16_mw_v7_5*.cu). */
+size_t fa_forward_splitkv_workspace_bytes(int B, int H, int Nq, int Nk, int d);
+int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
+                       int B, int H, int Nq, int Nk, int d, float scale,
+                       int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* 16x16 streaming family.  Replaces
  *   flashattn_streaming_16x16_kernel_mw(const __half* Q, const __half* K, const __half* V, float* O,
  *                                       int num_batches, int seq_len, float scale)

@@ -136,6 +136,37 @@ static void forward_rows_impl(const float* Q, const float* K, const float* V, fl
     }
 }
 
+/* Nq != Nk (no mask): the same row oracle, every query row over all Nk keys.  Q,O [BH,Nq,D];
+ * K,V [BH,Nk,D].  Not a reference function (the reference is self-attention); it IS the pinned row
+ * oracle applied with a different row count, and equals fa_oracle_forward when Nq == Nk. */
+void fa_oracle_forward_cross(const float* Q, const float* K, const float* V, float* O,
+                             int BH, int Nq, int Nk, int D, float scale, int accum, int nthreads)
+{
+    if (BH <= 0 || Nq <= 0 || Nk <= 0 || D <= 0) return;
+    const long nrows = (long)BH * Nq;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        float* w = (float*)malloc((size_t)Nk * sizeof(float));
+        double* od = (double*)malloc((size_t)D * sizeof(double));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (long r = 0; r < nrows; ++r) {
+            const int bh = (int)(r / Nq), i = (int)(r % Nq);
+            const float* q = Q + ((size_t)bh * Nq + i) * D;
+            float* o = O + ((size_t)bh * Nq + i) * D;
+            const size_t kb = (size_t)bh * Nk * D;
+            if (accum == 1) one_row_f64(q, K + kb, V + kb, o, Nk, D, scale, w, od);
+            else            one_row_f32(q, K + kb, V + kb, o, Nk, D, scale, w);
+        }
+        free(w);
+        free(od);
+    }
+}
+
 void fa_oracle_forward(const float* Q, const float* K, const float* V, float* O,
                        int BH, int N, int D, float scale, int accum, int nthreads)
 {

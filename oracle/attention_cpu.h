@@ -39,6 +39,10 @@ void fa_oracle_forward_causal_rows(const float* Q, const float* K, const float* 
                                    int BH, int N, int D, float scale, int accum, int nthreads,
                                    int bh0, int bh1, int row0, int row1);
 
+/* Nq != Nk, no mask: Q,O [BH,Nq,D]; K,V [BH,Nk,D] (the row oracle over all Nk keys; see the .c file). */
+void fa_oracle_forward_cross(const float* Q, const float* K, const float* V, float* O,
+                             int BH, int Nq, int Nk, int D, float scale, int accum, int nthreads);
+
 /* 16x16 streaming family oracle: Q [B,16,16], K [B,16,L] (k-major), V [B,L,16], O [B,16,16];
  * softmax normalised as 1/(sum + 1e-6), running max seeded with -1e30
  * (Streaming_FlashAttention_Forward_Kernel/flashattn_streaming_16x16_mw.cu:252-317). */

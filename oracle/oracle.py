@@ -45,6 +45,7 @@ def lib() -> C.CDLL:
         L.fa_oracle_forward.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         L.fa_oracle_forward_rows.argtypes = L.fa_oracle_forward.argtypes + [C.c_int] * 4
         L.fa_oracle_forward_causal_rows.argtypes = L.fa_oracle_forward_rows.argtypes
+        L.fa_oracle_forward_cross.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
         L.fa_oracle_streaming_16x16.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float]
         L.fa_oracle_transpose_k_16.argtypes = [_fp, _fp, C.c_int, C.c_int]
         L.fa_oracle_fill.argtypes = [_fp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
@@ -123,6 +124,21 @@ def forward(q, k, v, scale=None, accum: int = 0, nthreads: int = 1, bh_range=Non
     r0, r1 = row_range if row_range else (0, n)
     fn = lib().fa_oracle_forward_causal_rows if causal else lib().fa_oracle_forward_rows
     fn(_f(q), _f(k), _f(v), _f(o), bh, n, d, float(scale), accum, nthreads, b0, b1, r0, r1)
+    return o
+
+
+def forward_cross(q, k, v, scale=None, accum: int = 0, nthreads: int = 1):
+    """q [BH,Nq,D], k/v [BH,Nk,D] fp32 (already 16-bit-rounded) -> o [BH,Nq,D]; no mask."""
+    q = np.ascontiguousarray(q, np.float32)
+    k = np.ascontiguousarray(k, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    bh, nq, d = q.shape
+    nk = k.shape[1]
+    assert k.shape == (bh, nk, d) and v.shape == (bh, nk, d)
+    if scale is None:
+        scale = 1.0 / np.sqrt(np.float32(d))
+    o = np.zeros_like(q)
+    lib().fa_oracle_forward_cross(_f(q), _f(k), _f(v), _f(o), bh, nq, nk, d, float(scale), accum, nthreads)
     return o
 
 

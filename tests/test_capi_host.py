@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "fa_mi355.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return re.findall(r"\b(?:int|const char\*)\s+(\w+)\s*\(", text)
+    return re.findall(r"\b(?:int|size_t|const char\*)\s+(\w+)\s*\(", text)
 
 
 def test_header_symbols_exported(fa):
@@ -46,6 +46,12 @@ def test_invalid_arguments_rejected_without_device(fa):
     assert L.fa_forward_causal(p, p, p, p, 1, 1, 128, 64, 0.125, 0, 0, 5, None) == INVALID   # only AUTO/GENERIC/TILED/W64
     assert L.fa_forward_causal(p, p, p, p, 1, 1, 128, 32, 0.125, 0, 0, 2, None) == INVALID   # tiled needs D in {64,128}
     assert L.fa_forward_causal(null, p, p, p, 1, 1, 128, 64, 0.125, 0, 0, 0, None) == INVALID
+    assert L.fa_forward_splitkv(p, p, p, p, 1, 1, 1, 4096, 32, 0.125, 0, 0, None, 0, None) == INVALID    # d in {64,128}
+    assert L.fa_forward_splitkv(p, p, p, p, 1, 1, 0, 4096, 64, 0.125, 0, 0, None, 0, None) == INVALID
+    assert L.fa_forward_splitkv(p, p, p, p, 1, 1, 1, 8192, 64, 0.125, 0, 0, None, 0, None) == INVALID    # split needs a workspace
+    assert L.fa_forward_splitkv_workspace_bytes(1, 1, 1, 8192, 64) > 0
+    assert L.fa_forward_splitkv_workspace_bytes(8, 16, 4096, 4096, 64) == 0                             # enough workgroups already
+    assert L.fa_forward_splitkv_workspace_bytes(0, 1, 1, 8192, 64) == 0
     assert L.flashattn_streaming_16x16_mw(p, p, p, p, 0, 128, 0.25, None) == INVALID
     assert L.flashattn_streaming_16x16_mw(p, p, null, p, 4, 128, 0.25, None) == INVALID
     assert L.flashattn_streaming_16x16_mw_kt(p, p, p, p, 4, 0, 0.25, None) == INVALID

@@ -408,3 +408,57 @@ def test_sdpa_like_matches_torch_sdpa(fa, torch_cuda):
         want = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float(), is_causal=causal)
         assert got.dtype == torch.float16
         assert (got.float() - want).abs().max().item() <= MAX_ABS
+
+
+# ---- Nq != Nk with a split over the keys (not a reference entry point) -----------
+def _run_splitkv(fa, torch, qb, kb, vb, fmt, out_same=False, scale=None):
+    q, k, v = (_to_dev(torch, x[None], fmt) for x in (qb, kb, vb))   # B = 1, H = BH
+    od = _tdtype(torch, fmt) if out_same else torch.float32
+    o = fa.fa_forward_splitkv(q, k, v, scale=scale, out_dtype=od)
+    torch.cuda.synchronize()
+    return o[0].float().cpu().numpy()
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("d", [64, 128])
+def test_splitkv_vs_oracle(fa, oracle, torch_cuda, fmt, d):
+    """Few query rows against short, ragged and long K/V: the one-pass (S = 1) and the split + merge
+    paths, both output types."""
+    for bh, nq, nk in ((3, 1, 64), (2, 5, 100), (2, 16, 1000), (1, 130, 777), (4, 1, 8192 + 37), (16, 3, 4096)):
+        (q, _, _), (qb, _, _) = oracle.make_qkv(bh, nq, d, fmt=fmt, seed=10 + nq)
+        (_, k, v), (_, kb, vb) = oracle.make_qkv(bh, nk, d, fmt=fmt, seed=20 + nk)
+        want = oracle.forward_cross(q, k, v, nthreads=8)
+        got = _run_splitkv(fa, torch_cuda, qb, kb, vb, fmt)
+        _check(oracle, got, want, fmt, f"splitkv d={d} bh={bh} nq={nq} nk={nk} fmt={fmt}")
+        got = _run_splitkv(fa, torch_cuda, qb, kb, vb, fmt, out_same=True)
+        _check(oracle, got, want, fmt, f"splitkv d={d} nq={nq} nk={nk} out=same", out_same=True)
+    assert fa.splitkv_workspace_bytes(1, 4, 1, 8192 + 37, d) > 0      # that case really was split
+    assert fa.splitkv_workspace_bytes(1, 3, 1, 64, d) == 0             # and that one was not
+
+
+def test_splitkv_equals_plain_forward_on_square_shapes(fa, oracle, torch_cuda):
+    """Nq == Nk: same answer as fa_forward (different kernels, so to rounding, not bit-exact), and a
+    spiking key in the LAST chunk must win the merge (the per-chunk reference maxima differ by > 2^8)."""
+    bh, n, d = 2, 2048, 64
+    (q, k, v), _ = oracle.make_qkv(bh, n, d, fmt=0, seed=8)
+    k[:, n - 3] = q[:, 7] * 9.0
+    q, k = (oracle.decode16(oracle.encode16(x, 0), 0) for x in (q, k))
+    qb, kb, vb = (oracle.encode16(x, 0) for x in (q, k, v))
+    assert fa.splitkv_workspace_bytes(1, bh, n, n, d) > 0
+    a = _run_splitkv(fa, torch_cuda, qb, kb, vb, 0)
+    b = _run(fa, torch_cuda, qb, kb, vb, 0)
+    assert np.abs(a - b).max() <= 2e-3
+    want = oracle.forward_cross(q, k, v, nthreads=8)
+    _check(oracle, a, want, 0, "splitkv square with a late spike")
+
+
+def test_splitkv_rejects_a_short_workspace(fa, torch_cuda):
+    torch = torch_cuda
+    q = torch.zeros(1, 4, 1, 64, dtype=torch.float16, device="cuda")
+    k = torch.zeros(1, 4, 8192, 64, dtype=torch.float16, device="cuda")
+    need = fa.splitkv_workspace_bytes(1, 4, 1, 8192, 64)
+    assert need > 0
+    with pytest.raises(fa.FaError):
+        fa.fa_forward_splitkv(q, k, k, workspace=torch.empty(need - 1, dtype=torch.uint8, device="cuda"))
+    fa.fa_forward_splitkv(q, k, k, workspace=torch.empty(need, dtype=torch.uint8, device="cuda"))
+    torch.cuda.synchronize()
