@@ -22,6 +22,7 @@ SYMBOLS = (
     "fa_forward_causal",
     "fa_forward_splitkv_workspace_bytes",
     "fa_forward_splitkv",
+    "fa_debug_stage",
     "flashattn_streaming_16x16_mw",
     "flashattn_streaming_16x16_mw_kt",
     "fa_mi355_version",
@@ -79,6 +80,7 @@ def lib() -> C.CDLL:
         L.fa_forward_causal.argtypes = [vp, vp, vp, vp, i, i, i, i, f, i, i, i, vp]
         L.fa_forward_splitkv.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, i, i, vp, C.c_size_t, vp]
         L.fa_forward_splitkv_workspace_bytes.argtypes = [i, i, i, i, i]
+        L.fa_debug_stage.argtypes = [i, vp, vp, vp, i, i, i, f, i, vp]
         L.flashattn_streaming_16x16_mw.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         L.flashattn_streaming_16x16_mw_kt.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         for s in SYMBOLS[:-1]:

@@ -12,6 +12,8 @@ hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, 
 hipError_t split_dispatch(const void* Q, const void* K, const void* V, void* O, void* ws, size_t ws_bytes,
                           int BH, int Nq, int Nk, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream);
 size_t split_workspace_bytes(int BH, int Nq, int Nk, int D);
+hipError_t debug_stage_dispatch(int stage, const void* A, const void* B, void* Out, int BH, int N, int D, float scale,
+                                int dtype, hipStream_t stream);
 hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
                                 int num_batches, int seq_len, float scale, bool k_transposed,
                                 hipStream_t stream);
@@ -85,6 +87,12 @@ int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
     if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
     return (int)fa::split_dispatch(Q, K, V, O, workspace, workspace_bytes, B * H, Nq, Nk, d, scale, in_dtype, out_dtype,
                                    static_cast<hipStream_t>(stream));
+}
+
+int fa_debug_stage(int stage, const void* A, const void* B, void* Out, int BH, int N, int d, float scale,
+                   int dtype, void* stream)
+{
+    return (int)fa::debug_stage_dispatch(stage, A, B, Out, BH, N, d, scale, dtype, static_cast<hipStream_t>(stream));
 }
 
 int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,

@@ -84,6 +84,16 @@ int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
                        int B, int H, int Nq, int Nk, int d, float scale,
                        int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stage-level debug entry (cf. the reference's single-stage experiments
+ * FlashAttention/t16/ *debug*.cu): one stage of the tiled forward with its result in memory, through
+ * the same LDS images, fragment loads and accumulator maps as the product kernels.  d in {64,128}.
+ *   stage 1: A = Q, B = K [BH,N,d] 16-bit          -> Out = S = scale*Q.K^T  [BH,N,N] fp32
+ *   stage 2: A = S [BH,N,N] fp32, B = NULL         -> Out = P = softmax rows of S, 16-bit [BH,N,N]
+ *   stage 3: A = P [BH,N,N] 16-bit, B = V [BH,N,d] -> Out = O = P.V  [BH,N,d] fp32
+ * Not a product path and not tuned. */
+int fa_debug_stage(int stage, const void* A, const void* B, void* Out, int BH, int N, int d, float scale,
+                   int dtype, void* stream);
+
 /* 16x16 streaming family.  Replaces
  *   flashattn_streaming_16x16_kernel_mw(const __half* Q, const __half* K, const __half* V, float* O,
  *                                       int num_batches, int seq_len, float scale)

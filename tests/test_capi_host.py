@@ -52,6 +52,9 @@ def test_invalid_arguments_rejected_without_device(fa):
     assert L.fa_forward_splitkv_workspace_bytes(1, 1, 1, 8192, 64) > 0
     assert L.fa_forward_splitkv_workspace_bytes(8, 16, 4096, 4096, 64) == 0                             # enough workgroups already
     assert L.fa_forward_splitkv_workspace_bytes(0, 1, 1, 8192, 64) == 0
+    assert L.fa_debug_stage(0, p, p, p, 1, 128, 64, 0.125, 0, None) == INVALID
+    assert L.fa_debug_stage(1, p, p, p, 1, 128, 32, 0.125, 0, None) == INVALID
+    assert L.fa_debug_stage(3, p, null, p, 1, 128, 64, 0.125, 0, None) == INVALID
     assert L.flashattn_streaming_16x16_mw(p, p, p, p, 0, 128, 0.25, None) == INVALID
     assert L.flashattn_streaming_16x16_mw(p, p, null, p, 4, 128, 0.25, None) == INVALID
     assert L.flashattn_streaming_16x16_mw_kt(p, p, p, p, 4, 0, 0.25, None) == INVALID

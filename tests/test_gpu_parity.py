@@ -462,3 +462,42 @@ def test_splitkv_rejects_a_short_workspace(fa, torch_cuda):
         fa.fa_forward_splitkv(q, k, k, workspace=torch.empty(need - 1, dtype=torch.uint8, device="cuda"))
     fa.fa_forward_splitkv(q, k, k, workspace=torch.empty(need, dtype=torch.uint8, device="cuda"))
     torch.cuda.synchronize()
+
+
+# ---- stage-level debug kernels: each stage alone, against numpy ---------------
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("d", [64, 128])
+def test_debug_stages(fa, oracle, torch_cuda, fmt, d):
+    """QK^T-only, softmax-only and PV-only, each through the product kernels' LDS images and MFMA
+    fragment maps: a layout bug shows up in exactly one of the three."""
+    torch = torch_cuda
+    bh, n = 2, 200   # ragged: 200 = 3 tiles + 8 keys, 1.56 query blocks
+    (q, k, v), (qb, kb, vb) = oracle.make_qkv(bh, n, d, fmt=fmt, seed=321)
+    dq, dk, dv = (_to_dev(torch, x, fmt) for x in (qb, kb, vb))
+    L = fa.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    scale = 1.0 / np.sqrt(d)
+    # stage 1
+    s_dev = torch.full((bh, n, n), float("nan"), dtype=torch.float32, device="cuda")
+    assert L.fa_debug_stage(1, dq.data_ptr(), dk.data_ptr(), s_dev.data_ptr(), bh, n, d, scale, fmt, st) == 0
+    s_want = np.einsum("bid,bjd->bij", q.astype(np.float64), k.astype(np.float64)) * scale
+    s_got = s_dev.cpu().numpy()
+    assert np.abs(s_got - s_want).max() <= 2e-5 * max(1.0, np.abs(s_want).max())
+    # stage 2 (from the exact S so that the stages are judged independently)
+    s_in = torch.from_numpy(s_want.astype(np.float32)).cuda()
+    p_dev = torch.zeros((bh, n, n), dtype=_tdtype(torch, fmt), device="cuda")
+    assert L.fa_debug_stage(2, s_in.data_ptr(), None, p_dev.data_ptr(), bh, n, d, 0.0, fmt, st) == 0
+    w = np.exp(s_want - s_want.max(-1, keepdims=True))
+    p_want = w / w.sum(-1, keepdims=True)
+    p_got = p_dev.float().cpu().numpy()
+    assert np.abs(p_got - p_want).max() <= (2.0 ** -10 if fmt == 0 else 2.0 ** -7) * p_want.max()
+    assert np.abs(p_got.sum(-1) - 1.0).max() <= (2e-3 if fmt == 0 else 1e-2)
+    # stage 3 (from the rounded P the device produced)
+    o_dev = torch.full((bh, n, d), float("nan"), dtype=torch.float32, device="cuda")
+    assert L.fa_debug_stage(3, p_dev.data_ptr(), dv.data_ptr(), o_dev.data_ptr(), bh, n, d, 0.0, fmt, st) == 0
+    torch.cuda.synchronize()
+    o_want = np.einsum("bij,bjd->bid", p_got.astype(np.float64), v.astype(np.float64))
+    assert np.abs(o_dev.cpu().numpy() - o_want).max() <= 2e-5
+    # and the three chained agree with the fused kernel
+    fused = _run(fa, torch, qb, kb, vb, fmt)
+    assert np.abs(o_dev.cpu().numpy() - fused).max() <= (2e-3 if fmt == 0 else 1.5e-2)
