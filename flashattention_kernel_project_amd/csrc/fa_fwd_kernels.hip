@@ -443,6 +443,11 @@ template <typename T, bool kOutF32>
 static hipError_t dispatch_causal_d(const void* Q, const void* K, const void* V, void* O,
                                     int BH, int N, int D, float scale, int algo, hipStream_t stream)
 {
+    if (algo == 6) {   // 128-row workgroups, two per CU: finer diagonal, prologues overlap the neighbour's main loop
+        if (D == 64)  return launch_tiled<T, 64, kOutF32, 4, 2, true>(Q, K, V, O, BH, N, scale, stream);
+        if (D == 128) return launch_tiled<T, 128, kOutF32, 4, 2, true>(Q, K, V, O, BH, N, scale, stream);
+        return hipErrorInvalidValue;
+    }
     if (algo != 1) {
         if (D == 64)  return launch_tiled<T, 64, kOutF32, kWaves, 2, true>(Q, K, V, O, BH, N, scale, stream);
         if (D == 128) return launch_tiled<T, 128, kOutF32, kWaves, 2, true>(Q, K, V, O, BH, N, scale, stream);
@@ -538,7 +543,7 @@ hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, 
     if (!Q || !K || !V || !O) return hipErrorInvalidValue;
     if (BH <= 0 || N <= 0 || D <= 0 || D % 16 != 0 || D > kGenMaxD) return hipErrorInvalidValue;
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
-    if (algo != 0 && algo != 1 && algo != 2 && algo != 13) return hipErrorInvalidValue;
+    if (algo != 0 && algo != 1 && algo != 2 && algo != 6 && algo != 13) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     // algo 13: the 64-rows-per-wave kernel with the mask; measured 3-4 % SLOWER than the plain tiled kernel
     // under the mask (B8 H16 N4096 d64: 0.462 vs 0.443 ms; N8192 d128: 2.41 vs 2.36 ms), so AUTO stays tiled.
