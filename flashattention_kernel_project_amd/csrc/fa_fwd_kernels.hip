@@ -443,7 +443,9 @@ template <typename T, bool kOutF32>
 static hipError_t dispatch_causal_d(const void* Q, const void* K, const void* V, void* O,
                                     int BH, int N, int D, float scale, int algo, hipStream_t stream)
 {
-    if (algo == 6) {   // 128-row workgroups, two per CU: finer diagonal, prologues overlap the neighbour's main loop
+    // 128-row workgroups, two per CU: finer diagonal, prologues overlap the neighbour's main loop.  Measured
+    // B8 H16 N4096 d64: 0.375 ms against 0.442 (256-row) -> AUTO at d=64; N8192 d128: 2.40 vs 2.31 ms -> not at d=128.
+    if (algo == 6 || (algo == 0 && D == 64)) {
         if (D == 64)  return launch_tiled<T, 64, kOutF32, 4, 2, true>(Q, K, V, O, BH, N, scale, stream);
         if (D == 128) return launch_tiled<T, 128, kOutF32, 4, 2, true>(Q, K, V, O, BH, N, scale, stream);
         return hipErrorInvalidValue;

@@ -28,7 +28,7 @@ constexpr int kRows = 32 * kW;        // query rows per workgroup
 
 // kPartial: write (O^T unnormalised, m, l) to the workspace instead of the normalised output.
 template <typename T, int D, bool kOutF32, bool kPartial>
-__global__ __launch_bounds__(64 * split::kW, D == 64 ? 3 : 2)
+__global__ __launch_bounds__(64 * split::kW, D == 64 ? 4 : 2)
 void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                          const uint16_t* __restrict__ Vg, void* __restrict__ Og, float* __restrict__ ws,
                          int Nq, int Nk, int nqb, int S, int chunk, float scale_log2e)
@@ -57,6 +57,7 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
 
     constexpr int kLoadsW = (kBlockN * G::kChunks) / (64 * W);
     const unsigned q_row = qb * (unsigned)kRows + wave * 32u + r;
+    const bool has_rows = qb * (unsigned)kRows + wave * 32u < (unsigned)Nq;   // wave-uniform
 
     const float c = fabsf(scale_log2e);
     const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
@@ -121,6 +122,8 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
         const unsigned kv0 = key0 + (unsigned)t * kBlockN;
         if (t + 1 < ntiles) stage_load(kv0 + kBlockN);
 
+        // a wave whose 32 rows all lie past Nq (the usual case for a handful of query rows) only stages
+        if (has_rows) {
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -185,6 +188,7 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
                 }
                 o[db] = T::mfma32(vf, pk[ks], o[db]);
             }
+        }   // has_rows
 
         if (t + 1 < ntiles) stage_write(cur ^ 1u);
         __syncthreads();
@@ -271,12 +275,12 @@ void fa_split_combine_kernel(const float* __restrict__ ws, void* __restrict__ Og
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-// Number of key splits: enough workgroups to fill the chip about twice, at least 4 tiles per split.
+// Number of key splits: enough workgroups for about four per CU, at least 4 tiles per split.
 int split_count(int BH, int Nq, int Nk)
 {
     const long long base = (long long)BH * ((Nq + split::kRows - 1) / split::kRows);
     const int tiles = (Nk + kBlockN - 1) / kBlockN;
-    long long s = (768 + base - 1) / base;
+    long long s = (1024 + base - 1) / base;   // about four workgroups per CU
     if (s > tiles / 4) s = tiles / 4;
     if (s < 1) s = 1;
     // every split must hold at least one key: chunk = ceil(tiles / s) tiles, recompute s from the chunk

@@ -62,8 +62,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
 {
     using namespace w64;
     using G = TileGeom<D>;
-    // the causal d=64 instantiation is 12 VGPRs over budget with the 3-deep fragment ring: read one ahead there
-    constexpr int kAhead = (kCausal && X == 2) ? 1 : w64::kAhead, kRing = kAhead + 1;
+    constexpr int kAhead = w64::kAhead, kRing = kAhead + 1;
     constexpr int kRows = 32 * X * kW;                              // query rows per workgroup
     constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);      // 16-B K (and V) chunks per thread and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][K tile][V tile]
@@ -380,11 +379,14 @@ static hipError_t w64_dispatch_impl(const void* Q, const void* K, const void* V,
     if (D != 64 && D != 128) return hipErrorInvalidValue;
     if ((unsigned long long)(N + 64 * w64::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (D == 64) {
+        // under the mask: one 32-row block per wave (256-row workgroups): twice the items to balance, a
+        // finer diagonal, and no spills (the two-block causal instantiation is 12 VGPRs over budget)
+        constexpr int X = kCausal ? 1 : 2;
         if (in_dtype == 0)
-            return out_dtype == 0 ? launch_w64<F16, 64, 2, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_w64<F16, 64, 2, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
-        return out_dtype == 0 ? launch_w64<BF16, 64, 2, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64<BF16, 64, 2, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
+            return out_dtype == 0 ? launch_w64<F16, 64, X, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64<F16, 64, X, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64<BF16, 64, X, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<BF16, 64, X, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
     }
     if (in_dtype == 0)
         return out_dtype == 0 ? launch_w64<F16, 128, 1, true, kCausal>(Q, K, V, O, BH, N, scale, stream)

@@ -43,7 +43,7 @@ def test_invalid_arguments_rejected_without_device(fa):
     assert L.fa_forward_ex(p, p, p, p, 1, 1, 128, 32, 0.125, 0, 0, 2, None) == INVALID  # tiled needs D in {64,128}
     assert L.fa_forward_ex(p, p, p, p, 1, 1, 128, 64, 0.125, 0, 0, 99, None) == INVALID
     assert L.fa_forward(p, p, p, p, 1, 1, 1 << 24, 128, 0.125, 0, 0, None) == INVALID  # per-head offsets must fit 32 bit
-    assert L.fa_forward_causal(p, p, p, p, 1, 1, 128, 64, 0.125, 0, 0, 5, None) == INVALID   # only AUTO/GENERIC/TILED/W64
+    assert L.fa_forward_causal(p, p, p, p, 1, 1, 128, 64, 0.125, 0, 0, 5, None) == INVALID   # only AUTO/GENERIC/TILED/2WG/W64
     assert L.fa_forward_causal(p, p, p, p, 1, 1, 128, 32, 0.125, 0, 0, 2, None) == INVALID   # tiled needs D in {64,128}
     assert L.fa_forward_causal(null, p, p, p, 1, 1, 128, 64, 0.125, 0, 0, 0, None) == INVALID
     assert L.fa_forward_splitkv(p, p, p, p, 1, 1, 1, 4096, 32, 0.125, 0, 0, None, 0, None) == INVALID    # d in {64,128}

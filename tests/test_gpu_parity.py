@@ -320,7 +320,7 @@ def test_causal_vs_oracle(fa, oracle, torch_cuda, fmt):
         for n in (1, 17, 64, 65, 255, 256, 257, 600):
             (q, k, v), (qb, kb, vb) = oracle.make_qkv(3, n, d, fmt=fmt, seed=900 + n + d)
             want = oracle.forward(q, k, v, causal=True, nthreads=8)
-            for algo in ((0, 1, 2, 13) if d in (64, 128) else (0, 1)):
+            for algo in ((0, 1, 2, 6, 13) if d in (64, 128) else (0, 1)):
                 got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt, algo=algo)
                 _check(oracle, got, want, fmt, f"causal d={d} n={n} algo={algo} fmt={fmt}")
             got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt, out_same=True)
