@@ -34,6 +34,9 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define FA_W64_DOT2 1   // row sums over the ROUNDED p, one v_dot2c per packed pair (bf16: needed for accuracy, fa_common.hpp;
                         // fp16: -1.1 % wall in THIS kernel's separate softmax phase, +2.6 % in the interleaved kernel)
 #endif
+#ifndef FA_W64_YOUNG_PRIO
+#define FA_W64_YOUNG_PRIO 0
+#endif
 #ifndef FA_W64_WAVES
 #define FA_W64_WAVES 8
 #endif
@@ -102,6 +105,10 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     const std::true_type yes{};
     const std::false_type no{};
 
+#if FA_W64_YOUNG_PRIO
+    // the SIMD arbitrates its two waves by age: give the later-dispatched half a static priority
+    if (wave >= kW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const unsigned nwg = total_wg;
     for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
     if (bid != blockIdx.x) __syncthreads();

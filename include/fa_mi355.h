@@ -66,7 +66,8 @@ int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
  * dtypes as fa_forward.  NOT a reference entry point: the reference has no mask; this is the first
  * "next" row of SURVEY.md 8(f) (cf. the runtime-M tail masking of
  * flashattn_warp_spc/flashattn_streaming_16x16_mw_v12d.cu:100-135).  algo: FA_ALGO_AUTO,
- * FA_ALGO_GENERIC or FA_ALGO_TILED (D in {64,128}). */
+ * FA_ALGO_GENERIC, FA_ALGO_TILED (256-row workgroups), 6 (the tiled kernel with 128-row workgroups, two
+ * per CU) or FA_ALGO_W64; the last three need D in {64,128}. */
 int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                       int B, int H, int N, int d, float scale,
                       int in_dtype, int out_dtype, int algo, void* stream);

@@ -501,3 +501,19 @@ def test_debug_stages(fa, oracle, torch_cuda, fmt, d):
     # and the three chained agree with the fused kernel
     fused = _run(fa, torch, qb, kb, vb, fmt)
     assert np.abs(o_dev.cpu().numpy() - fused).max() <= (2e-3 if fmt == 0 else 1.5e-2)
+
+
+def test_uniform_inputs_v12_drivers(fa, oracle, torch_cuda):
+    """The reference's v12 drivers draw U(-1,1) with seed 123 (flashattn_streaming_16x16_mw_v12f.cu:26-29,305):
+    the same distribution through the general-shape entry, every d=64 kernel, and the 16x16 family."""
+    (q, k, v), (qb, kb, vb) = oracle.make_qkv(4, 320, 64, fmt=0, seed=123, dist=oracle.UNIFORM)
+    want = oracle.forward(q, k, v, nthreads=8)
+    for algo in _algos_for(64):
+        _check(oracle, _run(fa, torch_cuda, qb, kb, vb, 0, algo), want, 0, f"uniform inputs algo={algo}")
+    nb, L = 64, 128
+    nq, nk = nb * 256, nb * 16 * L
+    qb16 = oracle.encode16(oracle.fill(nq, 123, 0, oracle.UNIFORM), 0).reshape(nb, 16, 16)
+    kb16 = oracle.encode16(oracle.fill(nk, 123, nq, oracle.UNIFORM), 0).reshape(nb, 16, L)
+    vb16 = oracle.encode16(oracle.fill(nk, 123, nq + nk, oracle.UNIFORM), 0).reshape(nb, L, 16)
+    want16 = oracle.streaming_16x16(*(oracle.decode16(x, 0) for x in (qb16, kb16, vb16)), scale=0.25)
+    _check(oracle, _s16_run(fa, torch_cuda, qb16, kb16, vb16, False), want16, 0, "s16 uniform inputs")
