@@ -34,6 +34,10 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define FA_W64_DOT2 1   // row sums over the ROUNDED p, one v_dot2c per packed pair (bf16: needed for accuracy, fa_common.hpp;
                         // fp16: -1.1 % wall in THIS kernel's separate softmax phase, +2.6 % in the interleaved kernel)
 #endif
+#ifndef FA_W64_BARRIER_EVERY
+#define FA_W64_BARRIER_EVERY 1   // tiles per workgroup barrier (measured: 1 and 2 tie within 0.3 %): 2 = ring of four K/V buffers, tile t+2 staged during
+                                 // tile t, one barrier per two tiles (waves drift by up to a tile); 1 = two buffers, one per tile
+#endif
 #ifndef FA_W64_YOUNG_PRIO
 #define FA_W64_YOUNG_PRIO 0
 #endif
@@ -149,35 +153,44 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
             l_part[x] = 0.0f;
         }
+        // ring of kSlotsR buffers, tile t in slot t % kSlotsR; tile t + kDist is fetched at the top of iteration t and
+        // written half way through its PV; a barrier closes every kDist-th iteration:
+        //   visibility: tile t+kDist is written in iteration t, first read in iteration t+kDist, a barrier lies between;
+        //   reuse: its slot held tile t-kDist, last read in iteration t-kDist, and a barrier lies between as well.
+        constexpr int kDist = FA_W64_BARRIER_EVERY, kSlotsR = 2 * kDist;
 #pragma unroll
-        for (int p = 0; p < kLoads; ++p) {
-            kst[p] = buf_load16(rk, st_goff[p]);
-            vst[p] = buf_load16(rv, st_goff[p]);
-        }
+        for (int pt = 0; pt < kDist; ++pt) {
 #pragma unroll
-        for (int p = 0; p < kLoads; ++p) {
-            lds_write16(smem, k_lds[p], kst[p]);
-            lds_write16(smem, v_lds[p], vst[p]);
+            for (int p = 0; p < kLoads; ++p) {
+                kst[p] = buf_load16(rk, (unsigned)pt * G::kTileBytes + st_goff[p]);
+                vst[p] = buf_load16(rv, (unsigned)pt * G::kTileBytes + st_goff[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                lds_write16(smem, (unsigned)pt * G::kBufBytes + k_lds[p], kst[p]);
+                lds_write16(smem, (unsigned)pt * G::kBufBytes + v_lds[p], vst[p]);
+            }
         }
         __syncthreads();
 
         for (int t = 0; t < ntiles_wg; ++t) {
-            const unsigned cur = (unsigned)t & 1u;
+            const unsigned cur = (unsigned)t % kSlotsR, land = (unsigned)(t + kDist) % kSlotsR;
+            const bool sync = ((t + 1) % kDist) == 0;
             // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
-                kst[p] = buf_load16(rk, (unsigned)(t + 1) * G::kTileBytes + st_goff[p]);
-                vst[p] = buf_load16(rv, (unsigned)(t + 1) * G::kTileBytes + st_goff[p]);
+                kst[p] = buf_load16(rk, (unsigned)(t + kDist) * G::kTileBytes + st_goff[p]);
+                vst[p] = buf_load16(rv, (unsigned)(t + kDist) * G::kTileBytes + st_goff[p]);
             }
 
             // causal: tiles wholly above this wave's rows contribute nothing (wave-uniform; tile 0 never is)
             if (kCausal && (unsigned)(t * kBlockN) > wave_row0 + 32u * X - 1u) {
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
-                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds[p], kst[p]);
-                    lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds[p], vst[p]);
+                    lds_write16(smem, land * G::kBufBytes + k_lds[p], kst[p]);
+                    lds_write16(smem, land * G::kBufBytes + v_lds[p], vst[p]);
                 }
-                __syncthreads();
+                if (sync) __syncthreads();
                 continue;
             }
 
@@ -299,16 +312,17 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
                 if constexpr (f == FA_W64_STAGE_AT * G::kDBlocks) {   // land the next tile in the other buffer (half way through PV)
 #pragma unroll
                     for (int p = 0; p < kLoads; ++p) {
-                        lds_write16(smem, (cur ^ 1u) * G::kBufBytes + k_lds[p], kst[p]);
-                        lds_write16(smem, (cur ^ 1u) * G::kBufBytes + v_lds[p], vst[p]);
+                        lds_write16(smem, land * G::kBufBytes + k_lds[p], kst[p]);
+                        lds_write16(smem, land * G::kBufBytes + v_lds[p], vst[p]);
                     }
                 }
 #pragma unroll
                 for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(frag[f % kRing], pk[x][ks], o[x][db]);
                 read_v(std::integral_constant<int, f + kAhead>{});
             });
-            __syncthreads();
+            if (sync) __syncthreads();
         }
+        if (kDist > 1) __syncthreads();   // the next pass / item rewrites the ring: everybody is done reading
     };
 
     run(no);
@@ -370,9 +384,9 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
     const long long cap = (long long)grid_cap * (8 / w64::kW);
     const unsigned grid = (nwg > cap && !kCausal) ? (unsigned)cap : (unsigned)nwg;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_W64_BARRIER_EVERY * G::kBufBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>), dim3(grid), dim3(64 * w64::kW), G::kLdsBytes, stream,
+    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>), dim3(grid), dim3(64 * w64::kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();
