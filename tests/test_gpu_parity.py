@@ -517,3 +517,27 @@ def test_uniform_inputs_v12_drivers(fa, oracle, torch_cuda):
     vb16 = oracle.encode16(oracle.fill(nk, 123, nq + nk, oracle.UNIFORM), 0).reshape(nb, L, 16)
     want16 = oracle.streaming_16x16(*(oracle.decode16(x, 0) for x in (qb16, kb16, vb16)), scale=0.25)
     _check(oracle, _s16_run(fa, torch_cuda, qb16, kb16, vb16, False), want16, 0, "s16 uniform inputs")
+
+
+def test_launchers_are_graph_capturable(fa, torch_cuda):
+    """The launchers only enqueue kernels on the caller's stream (no allocation, no sync), so a HIP
+    graph captured around them replays to the same bits -- plain, causal and split-KV paths."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q, k, v = (torch.randn(2, 4, 700, 64, generator=g, device="cuda").half() for _ in range(3))
+    q1 = q[:, :, :3].contiguous()
+    ws = torch.empty(max(fa.splitkv_workspace_bytes(2, 4, 3, 700, 64), 1), dtype=torch.uint8, device="cuda")
+    o = torch.empty(q.shape, dtype=torch.float32, device="cuda")
+    oc = torch.empty_like(o)
+    eager = (fa.fa_forward(q, k, v).clone(), fa.fa_forward(q, k, v, causal=True).clone(),
+             fa.fa_forward_splitkv(q1, k, v, workspace=ws).clone())
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fa.fa_forward(q, k, v, out=o)
+        fa.fa_forward(q, k, v, out=oc, causal=True)
+        os_ = fa.fa_forward_splitkv(q1, k, v, workspace=ws)
+    o.zero_(), oc.zero_(), os_.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o, eager[0]) and torch.equal(oc, eager[1]) and torch.equal(os_, eager[2])
