@@ -136,4 +136,11 @@ __device__ __forceinline__ float swap_halves(float x) {
     return __shfl_xor(x, 32, 64);
 }
 
+// Dynamic LDS above the 64-KB default needs a per-function opt-in, and the attribute is per DEVICE: a
+// process that drives several GPUs (bench/fa_bench --gpus G) must set it on each, so no static caching.
+static inline hipError_t ensure_dyn_lds(const void* kernel, int bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 }  // namespace fa

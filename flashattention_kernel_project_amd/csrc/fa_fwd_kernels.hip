@@ -398,13 +398,8 @@ static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void
 {
     using G = TileGeom<D>;
     auto kern = fa_fwd_kernel<T, D, kOutF32, W, kOcc, kCausal>;
-    static bool attr_set = false;   // dyn-LDS opt-in is per function, cached (SURVEY 8(b) "Ownership")
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), G::kLdsBytes);
+    if (attr != hipSuccess) return attr;
     const int nqb = (N + 32 * W - 1) / (32 * W);
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;

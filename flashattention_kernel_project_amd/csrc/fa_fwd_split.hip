@@ -307,13 +307,8 @@ static hipError_t launch_split(const void* Q, const void* K, const void* V, void
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     if (S > 1 && (!ws || ws_bytes < split_workspace_bytes(BH, Nq, Nk, D))) return hipErrorInvalidValue;
     const uint16_t *q = static_cast<const uint16_t*>(Q), *k = static_cast<const uint16_t*>(K), *v = static_cast<const uint16_t*>(V);
-    static const hipError_t attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_split_kernel<T, D, kOutF32, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_split_kernel<T, D, kOutF32, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsBytes);
-    }();
+    hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_split_kernel<T, D, kOutF32, false>), G::kLdsBytes);
+    if (attr == hipSuccess) attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_split_kernel<T, D, kOutF32, true>), G::kLdsBytes);
     if (attr != hipSuccess) return attr;
     if (S == 1) {
         hipLaunchKernelGGL((fa_fwd_split_kernel<T, D, kOutF32, false>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,

@@ -383,8 +383,8 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
     }();
     const long long cap = (long long)grid_cap * (8 / w64::kW);
     const unsigned grid = (nwg > cap && !kCausal) ? (unsigned)cap : (unsigned)nwg;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_W64_BARRIER_EVERY * G::kBufBytes);
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>),
+                                           2 * FA_W64_BARRIER_EVERY * G::kBufBytes);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>), dim3(grid), dim3(64 * w64::kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),

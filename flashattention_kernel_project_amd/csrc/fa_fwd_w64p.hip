@@ -430,8 +430,7 @@ static hipError_t launch_w64p(const void* Q, const void* K, const void* V, void*
         return cus;
     }();
     const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_w64p_kernel<T, kOutF32>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, w64p::kSlots * G::kBufBytes);
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64p_kernel<T, kOutF32>), w64p::kSlots * G::kBufBytes);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((fa_fwd_w64p_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64p::kW),
                        w64p::kSlots * G::kBufBytes, stream,
