@@ -95,6 +95,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
 }
+// read-once streams (decode K/V): non-temporal hint (cache-policy bit 1 = nt on gfx94x/gfx950)
+__device__ __forceinline__ u32x4 buf_load16_nt(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 2);
+}
 __device__ __forceinline__ u32x2 buf_load8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
 }
@@ -103,6 +107,12 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned v
 }
 __device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x2 v) {
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store16_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 2);
+}
+__device__ __forceinline__ void buf_store8_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 2);
 }
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned v) {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, 0, 0);

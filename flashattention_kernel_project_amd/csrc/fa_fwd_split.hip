@@ -21,6 +21,9 @@
 
 namespace fa {
 
+#ifndef FA_SPLIT_NT
+#define FA_SPLIT_NT 1   // K/V are read exactly once: non-temporal loads (5.97 -> 6.75 TB/s at B8 H16 Nq1 Nk32768 d128)
+#endif
 namespace split {
 constexpr int kW = 4;                 // waves per workgroup
 constexpr int kRows = 32 * kW;        // query rows per workgroup
@@ -83,8 +86,13 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
     auto stage_load = [&](unsigned kv0) {
 #pragma unroll
         for (int p = 0; p < kLoadsW; ++p) {
+#if FA_SPLIT_NT
+            kst[p] = buf_load16_nt(rk, kv0 * G::kRowBytes + g_off[p]);
+            vst[p] = buf_load16_nt(rv, kv0 * G::kRowBytes + g_off[p]);
+#else
             kst[p] = buf_load16(rk, kv0 * G::kRowBytes + g_off[p]);
             vst[p] = buf_load16(rv, kv0 * G::kRowBytes + g_off[p]);
+#endif
         }
     };
     auto stage_write = [&](unsigned buf) {

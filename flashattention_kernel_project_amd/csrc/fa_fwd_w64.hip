@@ -38,6 +38,9 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define FA_W64_BARRIER_EVERY 1   // tiles per workgroup barrier (measured: 1 and 2 tie within 0.3 %): 2 = ring of four K/V buffers, tile t+2 staged during
                                  // tile t, one barrier per two tiles (waves drift by up to a tile); 1 = two buffers, one per tile
 #endif
+#ifndef FA_W64_NT
+#define FA_W64_NT 0   // 1: non-temporal O stores, 2: also non-temporal Q loads
+#endif
 #ifndef FA_W64_YOUNG_PRIO
 #define FA_W64_YOUNG_PRIO 0
 #endif
@@ -135,7 +138,8 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     for (int x = 0; x < X; ++x)
 #pragma unroll
         for (int s = 0; s < G::kKSteps; ++s) {
-            u32x4 raw = buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
+            u32x4 raw = FA_W64_NT >= 2 ? buf_load16_nt(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u)
+                                       : buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
 #pragma unroll
             for (int w = 0; w < 4; ++w) raw[w] ^= q_flip;
             qf[x][s] = raw;
@@ -357,10 +361,12 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
                 const float cc = o[x][db][4 * g + 2] * inv, d = o[x][db][4 * g + 3] * inv;
                 if constexpr (kOutF32) {
                     const f32x4 v = {a, b, cc, d};
-                    buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+                    if constexpr (FA_W64_NT >= 1) buf_store16_nt(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+                    else buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
                 } else {
                     const u32x2 v = {T::pack2(a, b), T::pack2(cc, d)};
-                    buf_store8(ro, (row * D + col) * 2u, v);
+                    if constexpr (FA_W64_NT >= 1) buf_store8_nt(ro, (row * D + col) * 2u, v);
+                    else buf_store8(ro, (row * D + col) * 2u, v);
                 }
             }
     }

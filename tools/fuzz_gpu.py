@@ -74,6 +74,10 @@ def main():
         # (3, 4, 9, 10, 11, 12) reproduce |V| * 2^-9 of the dominant weight's rounding.
         vmax = v.float().abs().max().item()
         tol = 1e-2
+        if dt == torch.bfloat16 and spread > 2:
+            # sharply peaked rows with two or three comparable dominant weights: each bf16 weight carries 2^-9
+            # relative rounding, so O moves by up to 2^-9 * (spread of the dominant V rows) -- the format's limit
+            tol += vmax * 2.0 ** -9
         if out_same:
             tol += vmax * (2.0 ** -9 if dt == torch.bfloat16 else 2.0 ** -12)
         if dt == torch.bfloat16 and kind != "split" and algo in (3, 4, 9, 10, 11, 12):
