@@ -95,6 +95,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
 }
+// explicit cache policy (gfx94x/gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+template <int kAux>
+__device__ __forceinline__ u32x4 buf_load16_cp(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, kAux);
+}
 // read-once streams (decode K/V): non-temporal hint (cache-policy bit 1 = nt on gfx94x/gfx950)
 __device__ __forceinline__ u32x4 buf_load16_nt(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 2);

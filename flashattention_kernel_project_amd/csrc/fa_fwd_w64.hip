@@ -38,6 +38,9 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define FA_W64_BARRIER_EVERY 1   // tiles per workgroup barrier (measured: 1 and 2 tie within 0.3 %): 2 = ring of four K/V buffers, tile t+2 staged during
                                  // tile t, one barrier per two tiles (waves drift by up to a tile); 1 = two buffers, one per tile
 #endif
+#ifndef FA_W64_KV_AUX
+#define FA_W64_KV_AUX 0   // cache-policy bits of the K/V staging loads (1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef FA_W64_NT
 #define FA_W64_NT 0   // 1: non-temporal O stores, 2: also non-temporal Q loads
 #endif
@@ -183,8 +186,8 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
             // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
-                kst[p] = buf_load16(rk, (unsigned)(t + kDist) * G::kTileBytes + st_goff[p]);
-                vst[p] = buf_load16(rv, (unsigned)(t + kDist) * G::kTileBytes + st_goff[p]);
+                kst[p] = buf_load16_cp<FA_W64_KV_AUX>(rk, (unsigned)(t + kDist) * G::kTileBytes + st_goff[p]);
+                vst[p] = buf_load16_cp<FA_W64_KV_AUX>(rv, (unsigned)(t + kDist) * G::kTileBytes + st_goff[p]);
             }
 
             // causal: tiles wholly above this wave's rows contribute nothing (wave-uniform; tile 0 never is)
