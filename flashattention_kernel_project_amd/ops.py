@@ -96,14 +96,20 @@ def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = 
 
 
 def fa_forward_splitkv(q, k, v, scale: float | None = None, out_dtype=None, workspace=None, stream=None):
-    """q [B,H,Nq,d], k/v [B,H,Nk,d] fp16/bf16 device tensors, no mask, d in {64,128}: the key axis is
+    """q [B,Hq,Nq,d], k/v [B,Hkv,Nk,d] fp16/bf16 device tensors, no mask, d in {64,128}: the key axis is
     cut into chunks that run in parallel and are merged (fa_forward_splitkv, "flash-decoding").
-    workspace: optional uint8 device tensor of at least splitkv_workspace_bytes(...); allocated if None."""
+    Hq may be a multiple of Hkv (grouped-query attention): the G = Hq/Hkv query heads of a group are
+    contiguous in q, so the group is passed to the C ABI as ONE head with G*Nq query rows and its K/V is
+    streamed once for all of them -- no copy, same kernel.
+    workspace: optional uint8 device tensor of at least splitkv_workspace_bytes(B, Hkv, G*Nq, Nk, d)."""
     import torch
-    if q.dim() != 4 or k.dim() != 4 or v.shape != k.shape or q.shape[:2] != k.shape[:2] or q.shape[3] != k.shape[3]:
-        raise ValueError("q must be [B,H,Nq,d] and k, v [B,H,Nk,d]")
-    B, H, Nq, d = q.shape
-    Nk = k.shape[2]
+    if q.dim() != 4 or k.dim() != 4 or v.shape != k.shape or q.shape[0] != k.shape[0] or q.shape[3] != k.shape[3]:
+        raise ValueError("q must be [B,Hq,Nq,d] and k, v [B,Hkv,Nk,d]")
+    B, Hq, Nq, d = q.shape
+    H, Nk = k.shape[1], k.shape[2]
+    if Hq % H != 0:
+        raise ValueError("the number of query heads must be a multiple of the number of K/V heads")
+    rows = (Hq // H) * Nq   # query rows that share one K/V head
     if q.dtype not in (torch.float16, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
         raise ValueError("q, k, v must all be fp16 or all bf16")
     in_dt = capi.F16 if q.dtype == torch.float16 else capi.BF16
@@ -111,7 +117,7 @@ def fa_forward_splitkv(q, k, v, scale: float | None = None, out_dtype=None, work
     if out_dtype not in (torch.float32, q.dtype):
         raise ValueError("out_dtype must be torch.float32 or the input dtype")
     out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
-    need = splitkv_workspace_bytes(B, H, Nq, Nk, d)
+    need = splitkv_workspace_bytes(B, H, rows, Nk, d)
     if workspace is None and need:
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
     ws_ptr, ws_len = (workspace.data_ptr(), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
@@ -120,7 +126,7 @@ def fa_forward_splitkv(q, k, v, scale: float | None = None, out_dtype=None, work
     dts = (torch.float16, torch.bfloat16)
     code = capi.lib().fa_forward_splitkv(
         _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts), _dev_ptr(out, "out", (out_dtype,)),
-        B, H, Nq, Nk, d, float(scale), in_dt, capi.OUT_F32 if out_dtype == torch.float32 else capi.OUT_SAME,
+        B, H, rows, Nk, d, float(scale), in_dt, capi.OUT_F32 if out_dtype == torch.float32 else capi.OUT_SAME,
         ws_ptr, ws_len, _stream_ptr(stream))
     capi.check("fa_forward_splitkv", code)
     return out

@@ -78,6 +78,9 @@ int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
  * from B*H, Nq, Nk), each chunk leaves an unnormalised partial result in `workspace`, and a second
  * small kernel merges them.  The caller owns the workspace (size from
  * fa_forward_splitkv_workspace_bytes(); 0 means S = 1 and `workspace` may be NULL).
+ * Grouped-query attention needs no separate entry: with Q [B,Hq,Nq,d] and K,V [B,Hkv,Nk,d], the
+ * G = Hq/Hkv query heads of a group are contiguous, so pass H = Hkv and Nq = G*Nq -- the group's K/V is
+ * then streamed once for all G heads.
  * NOT a reference entry point (cf. the single-query experiment
  * flashattn_warp_spc_2/flashattn_streaming_16x16_mw_v7_5*.cu). */
 size_t fa_forward_splitkv_workspace_bytes(int B, int H, int Nq, int Nk, int d);

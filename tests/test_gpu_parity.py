@@ -541,3 +541,25 @@ def test_launchers_are_graph_capturable(fa, torch_cuda):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(o, eager[0]) and torch.equal(oc, eager[1]) and torch.equal(os_, eager[2])
+
+
+def test_splitkv_grouped_query_heads(fa, oracle, torch_cuda):
+    """Hq = G * Hkv: each group of G query heads shares one K/V head (passed to the C ABI as one head
+    with G*Nq rows).  Against the oracle run with K/V repeated per query head."""
+    torch = torch_cuda
+    b, hq, hkv, nq, nk, d = 2, 8, 2, 1, 3000, 128
+    g = hq // hkv
+    (q, _, _), (qb, _, _) = oracle.make_qkv(b * hq, nq, d, fmt=0, seed=61)
+    (_, k, v), (_, kb, vb) = oracle.make_qkv(b * hkv, nk, d, fmt=0, seed=62)
+    want = oracle.forward_cross(q, np.repeat(k, g, axis=0), np.repeat(v, g, axis=0), nthreads=8)
+    dq = _to_dev(torch, qb, 0).view(b, hq, nq, d)
+    dk, dv = (_to_dev(torch, x, 0).view(b, hkv, nk, d) for x in (kb, vb))
+    got = fa.fa_forward_splitkv(dq, dk, dv)
+    torch.cuda.synchronize()
+    _check(oracle, got.view(b * hq, nq, d).float().cpu().numpy(), want, 0, "splitkv GQA")
+    nq = 5   # several rows per head: row r of the merged head = (head r // nq, row r % nq)
+    (q, _, _), (qb, _, _) = oracle.make_qkv(b * hq, nq, d, fmt=0, seed=63)
+    want = oracle.forward_cross(q, np.repeat(k, g, axis=0), np.repeat(v, g, axis=0), nthreads=8)
+    got = fa.fa_forward_splitkv(_to_dev(torch, qb, 0).view(b, hq, nq, d), dk, dv)
+    torch.cuda.synchronize()
+    _check(oracle, got.view(b * hq, nq, d).float().cpu().numpy(), want, 0, "splitkv GQA nq=5")
