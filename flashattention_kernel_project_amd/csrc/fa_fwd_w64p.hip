@@ -40,7 +40,6 @@ __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 constexpr int kW = 8;              // waves per workgroup
-constexpr int kRows = 64 * kW;     // query rows per workgroup
 constexpr int kSlots = 4;          // LDS ring: tiles j-1 .. j+2
 constexpr int kAhead = 2;          // fragments read ahead of their MFMAs
 constexpr int kRing = 4;           // fragment registers (8 fragments per step: the phase repeats)
@@ -55,15 +54,20 @@ constexpr int kRing = 4;           // fragment registers (8 fragments per step: 
 #endif
 }  // namespace w64p
 
-template <typename T, bool kOutF32>
+// D = head dim (64 or 128), X = 32-row query blocks per wave (2 at D = 64, 1 at D = 128): a step is always
+// 16 MFMAs (2*kKSteps fragments, each feeding X MFMAs) beside the softmax of 16*X scores per lane.
+template <typename T, int D, int X, bool kOutF32>
 __global__ __launch_bounds__(64 * w64p::kW, 2)
 void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                         int N, int nqb, float scale_log2e, unsigned total_wg)
 {
     using namespace w64p;
-    constexpr int D = 64;
     using G = TileGeom<D>;
+    constexpr int kRows = 32 * X * kW;                          // query rows per workgroup
+    constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);  // 16-B K (and V) chunks per thread and tile
+    constexpr int kFrags = 2 * G::kKSteps;                      // fragments per step: K and V^T alternate
+    static_assert(kFrags * X == 16 && kFrags % kRing == 0, "a step is 16 MFMAs; the fragment ring phase must repeat");
     constexpr unsigned kSlotBytes = G::kBufBytes;   // [K tile][V tile]
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -76,11 +80,16 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const int ntiles = (N + kBlockN - 1) / kBlockN;
     const bool partial = (N % kBlockN) != 0;
 
-    // staging: one 16-B chunk of K and one of V per thread and tile
-    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
-    const unsigned st_goff = srow * G::kRowBytes + sch * 16u;
-    const unsigned k_lds = G::k_off(srow, sch);
-    const unsigned v_lds = G::kTileBytes + G::v_off(srow, sch);
+    // staging: kLoads 16-B chunks of K and of V per thread and tile
+    unsigned st_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
+#pragma unroll
+    for (int p = 0; p < kLoads; ++p) {
+        const unsigned idx = tid + p * 64u * kW;
+        const unsigned srow = idx / G::kChunks, sch = idx % G::kChunks;
+        st_goff[p] = srow * G::kRowBytes + sch * 16u;
+        k_lds[p] = G::k_off(srow, sch);
+        v_lds[p] = G::kTileBytes + G::v_off(srow, sch);
+    }
 
     const unsigned k_rd_row = r * G::kRowBytes;
     const unsigned k_rd_swz = G::k_swz(r);
@@ -112,11 +121,11 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
-    const unsigned q_row0 = qb * kRows + wave * 64u + r;   // query block 0; block 1 is 32 rows further
+    const unsigned q_row0 = qb * kRows + wave * (32u * X) + r;   // query block 0; block x is 32x rows further
 
-    u32x4 qf[2][G::kKSteps];
+    u32x4 qf[X][G::kKSteps];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < X; ++x)
 #pragma unroll
         for (int s = 0; s < G::kKSteps; ++s) {
             u32x4 raw = buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
@@ -125,9 +134,9 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             qf[x][s] = raw;
         }
 
-    f32x16 o[2][G::kDBlocks];
-    float m_ref[2] = {0.0f, 0.0f}, l_part[2] = {0.0f, 0.0f};
-    u32x4 kst, vst;
+    f32x16 o[X][G::kDBlocks];
+    float m_ref[X] = {}, l_part[X] = {};
+    u32x4 kst[kLoads], vst[kLoads];
     u32x4 frag[kRing];
 
     // LDS fragment addresses.  A K fragment of unit (tile slot offset `so`, key block kb), k-step ks;
@@ -145,16 +154,16 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
         return vf;
     };
-    // fragment f (0..7) of a step: even f -> K fragment ks = f/2 of the QK^T unit, odd f -> V^T
+    // fragment f (0..kFrags-1) of a step: even f -> K fragment ks = f/2 of the QK^T unit, odd f -> V^T
     // fragment (db = f/4, ks2 = (f/2)&1) of the PV unit
     auto read_frag = [&](auto fc, unsigned so_q, int kb_q, unsigned so_v, int kb_v) {
         constexpr int f = decltype(fc)::value;
         if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, kb_q, f >> 1);
         else frag[f % kRing] = read_vf(so_v, kb_v, f >> 2, (f >> 1) & 1);
     };
-    auto mask_unit = [&](int tile, int kb, f32x16 (&s)[2]) {   // keys >= N -> -inf (p = 0)
+    auto mask_unit = [&](int tile, int kb, f32x16 (&s)[X]) {   // keys >= N -> -inf (p = 0)
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < X; ++x)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = tile * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
@@ -175,16 +184,21 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // One step of the optimistic pass.  kb = key block of the unit being softmaxed (s_cur = its raw
     // scores -> pk_cur); the QK^T unit is (so_q, 1-kb) -> s_nxt, the PV unit (so_v, 1-kb) <- pk_prev.
     // `so_nq/so_nv`: slot offsets of the NEXT step's QK^T / PV units, for the fragments read ahead.
-    auto step = [&](auto kb_c, int tile, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[2][2],
-                    u32x4 (&pk_cur)[2][2], unsigned so_q, unsigned so_v, unsigned so_nq, unsigned so_nv,
+    auto step = [&](auto kb_c, int tile, f32x16 (&s_cur)[X], f32x16 (&s_nxt)[X], u32x4 (&pk_prev)[X][2],
+                    u32x4 (&pk_cur)[X][2], unsigned so_q, unsigned so_v, unsigned so_nq, unsigned so_nv,
                     unsigned so_land) __attribute__((always_inline)) {
         constexpr int kb = decltype(kb_c)::value, ko = 1 - kb;
         if (partial && tile + 1 == ntiles) mask_unit(tile, kb, s_cur);
 
-        constexpr int kSteps = 16;   // VALU pair-steps: pairs 0-7 query block 0, 8-15 query block 1
+        constexpr int kSteps = 8 * X;   // VALU pair-steps: pairs 8x .. 8x+7 belong to query block x
         const f32x2 c2 = {c, c};
-        const f32x2 nm[2] = {{-m_ref[0], -m_ref[0]}, {-m_ref[1], -m_ref[1]}};
-        float ls[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        f32x2 nm[X];
+        float ls[X][2];
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            nm[x] = f32x2{-m_ref[x], -m_ref[x]};
+            ls[x][0] = ls[x][1] = 0.0f;
+        }
         auto fma_pair = [&](auto jc) {
             constexpr int j = decltype(jc)::value, x = j >> 3, e = 2 * (j & 7);
             f32x2 v = {s_cur[x][e], s_cur[x][e + 1]};
@@ -215,7 +229,7 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             fin_pair(jc);
         };
         auto issue_mfma = [&](auto ic) {
-            constexpr int i = decltype(ic)::value, f = i >> 1, x = i & 1;
+            constexpr int i = decltype(ic)::value, f = i / X, x = i % X;
             if constexpr ((f & 1) == 0) {
                 constexpr int ks = f >> 1;
                 s_nxt[x] = T::mfma32(frag[f % kRing], qf[x][ks], ks == 0 ? zero16 : s_nxt[x]);
@@ -232,28 +246,33 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (kb == 1 && i == FA_W64P_STAGE_SLOT) {   // land tile j+2 (requested at the top of the iteration)
-                lds_write16(smem, so_land + k_lds, kst);
-                lds_write16(smem, so_land + v_lds, vst);
+#pragma unroll
+                for (int p = 0; p < kLoads; ++p) {
+                    lds_write16(smem, so_land + k_lds[p], kst[p]);
+                    lds_write16(smem, so_land + v_lds[p], vst[p]);
+                }
             }
             if constexpr (FA_W64P_SETPRIO) __builtin_amdgcn_s_setprio(1);
             issue_mfma(ic);
-            if constexpr ((i & 1) == 1) {   // the fragment just consumed twice is free: read two ahead
-                constexpr int f = (i >> 1) + kAhead;
-                if constexpr (f < 8) read_frag(std::integral_constant<int, f>{}, so_q, ko, so_v, ko);
-                else read_frag(std::integral_constant<int, f - 8>{}, so_nq, kb, so_nv, kb);
+            if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
+                constexpr int f = i / X + kAhead;
+                if constexpr (f < kFrags) read_frag(std::integral_constant<int, f>{}, so_q, ko, so_v, ko);
+                else read_frag(std::integral_constant<int, f - kFrags>{}, so_nq, kb, so_nv, kb);
             }
             if constexpr (FA_W64P_SETPRIO) __builtin_amdgcn_s_setprio(0);
-            valu_step(ic);
+            // VALU pair-steps [i*kSteps/16, (i+1)*kSteps/16): one per slot at X = 2, one per two slots at X = 1
+            constexpr int j0 = i * kSteps / 16, j1 = (i + 1) * kSteps / 16;
+            sfor<j1 - j0>([&](auto dj) { valu_step(std::integral_constant<int, j0 + decltype(dj)::value>{}); });
         });
         __builtin_amdgcn_sched_barrier(0);
-        l_part[0] += ls[0][0] + ls[0][1];
-        l_part[1] += ls[1][0] + ls[1][1];
+#pragma unroll
+        for (int x = 0; x < X; ++x) l_part[x] += ls[x][0] + ls[x][1];
     };
 
     // One step of the tracked (fallback) pass: same data flow in plain program order, with the lazy
     // running max per unit.  Speed is irrelevant here.
-    auto step_tracked = [&](auto kb_c, int tile, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], u32x4 (&pk_prev)[2][2],
-                            u32x4 (&pk_cur)[2][2], unsigned so_q, unsigned so_v, unsigned so_land) __attribute__((always_inline)) {
+    auto step_tracked = [&](auto kb_c, int tile, f32x16 (&s_cur)[X], f32x16 (&s_nxt)[X], u32x4 (&pk_prev)[X][2],
+                            u32x4 (&pk_cur)[X][2], unsigned so_q, unsigned so_v, unsigned so_land) __attribute__((always_inline)) {
         constexpr int kb = decltype(kb_c)::value, ko = 1 - kb;
         // O^T += V(u-1)^T.P(u-1)^T first: P(u-1) is in the scale of the current reference max
 #pragma unroll
@@ -261,12 +280,12 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
                 const u32x4 vf = read_vf(so_v, ko, db, ks2);
-                o[0][db] = T::mfma32(vf, pk_prev[0][ks2], o[0][db]);
-                o[1][db] = T::mfma32(vf, pk_prev[1][ks2], o[1][db]);
+#pragma unroll
+                for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(vf, pk_prev[x][ks2], o[x][db]);
             }
         if (partial && tile + 1 == ntiles) mask_unit(tile, kb, s_cur);
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < X; ++x) {
             const float tmax = row_max(s_cur[x]);
             if (__any(tmax - m_ref[x] > kThr)) {
                 const float m_new = fmaxf(tmax, m_ref[x]);
@@ -297,49 +316,59 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
         for (int ks = 0; ks < G::kKSteps; ++ks) {
             const u32x4 kf = read_kf(so_q, ko, ks);
-            s_nxt[0] = T::mfma32(kf, qf[0][ks], ks == 0 ? zero16 : s_nxt[0]);
-            s_nxt[1] = T::mfma32(kf, qf[1][ks], ks == 0 ? zero16 : s_nxt[1]);
+#pragma unroll
+            for (int x = 0; x < X; ++x) s_nxt[x] = T::mfma32(kf, qf[x][ks], ks == 0 ? zero16 : s_nxt[x]);
         }
         if constexpr (kb == 1) {
-            lds_write16(smem, so_land + k_lds, kst);
-            lds_write16(smem, so_land + v_lds, vst);
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                lds_write16(smem, so_land + k_lds[p], kst[p]);
+                lds_write16(smem, so_land + v_lds[p], vst[p]);
+            }
         }
     };
 
     auto run = [&](auto track_c) __attribute__((always_inline)) {
         constexpr bool kTrack = decltype(track_c)::value;
-        f32x16 sA[2], sB[2];
-        u32x4 pkA[2][2], pkB[2][2];
+        f32x16 sA[X], sB[X];
+        u32x4 pkA[X][2], pkB[X][2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < X; ++x) {
 #pragma unroll
             for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
             l_part[x] = 0.0f;
             pkB[x][0] = pkB[x][1] = zero4;   // "P(-1)" = 0 against the zeroed V of ring slot 3
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ------------
-        {
-            const u32x4 k0 = buf_load16(rk, st_goff), v0 = buf_load16(rv, st_goff);
-            const u32x4 k1 = buf_load16(rk, G::kTileBytes + st_goff), v1 = buf_load16(rv, G::kTileBytes + st_goff);
-            lds_write16(smem, 3u * kSlotBytes + v_lds, zero4);
-            lds_write16(smem, k_lds, k0);
-            lds_write16(smem, v_lds, v0);
-            lds_write16(smem, kSlotBytes + k_lds, k1);
-            lds_write16(smem, kSlotBytes + v_lds, v1);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                kst[p] = buf_load16(rk, (unsigned)pt * G::kTileBytes + st_goff[p]);
+                vst[p] = buf_load16(rv, (unsigned)pt * G::kTileBytes + st_goff[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                if (pt == 0) lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4);
+                lds_write16(smem, (unsigned)pt * kSlotBytes + k_lds[p], kst[p]);
+                lds_write16(smem, (unsigned)pt * kSlotBytes + v_lds[p], vst[p]);
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < G::kKSteps; ++ks) {   // S(unit 0)
             const u32x4 kf = read_kf(0u, 0, ks);
-            sA[0] = T::mfma32(kf, qf[0][ks], ks == 0 ? zero16 : sA[0]);
-            sA[1] = T::mfma32(kf, qf[1][ks], ks == 0 ? zero16 : sA[1]);
+#pragma unroll
+            for (int x = 0; x < X; ++x) sA[x] = T::mfma32(kf, qf[x][ks], ks == 0 ? zero16 : sA[x]);
         }
         {
             // reference max from the first 32 keys (masked copy when N < 32; the step masks again)
-            f32x16 s0[2] = {sA[0], sA[1]};
+            f32x16 s0[X];
+#pragma unroll
+            for (int x = 0; x < X; ++x) s0[x] = sA[x];
             if (partial && ntiles == 1) mask_unit(0, 0, s0);
-            m_ref[0] = row_max(s0[0]) + (kTrack ? 0.0f : kHeadroom);
-            m_ref[1] = row_max(s0[1]) + (kTrack ? 0.0f : kHeadroom);
+#pragma unroll
+            for (int x = 0; x < X; ++x) m_ref[x] = row_max(s0[x]) + (kTrack ? 0.0f : kHeadroom);
         }
         if constexpr (!kTrack) {   // fragments 0,1 of the first step: K(tile 0, kb 1), V("tile -1")
             read_frag(c0{}, 0u, 1, 3u * kSlotBytes, 1);
@@ -350,8 +379,11 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             const unsigned so_m1 = ((unsigned)(j + 3) & 3u) * kSlotBytes, so_0 = ((unsigned)j & 3u) * kSlotBytes;
             const unsigned so_p1 = ((unsigned)(j + 1) & 3u) * kSlotBytes, so_p2 = ((unsigned)(j + 2) & 3u) * kSlotBytes;
             // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
-            kst = buf_load16(rk, (unsigned)(j + 2) * G::kTileBytes + st_goff);
-            vst = buf_load16(rv, (unsigned)(j + 2) * G::kTileBytes + st_goff);
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                kst[p] = buf_load16(rk, (unsigned)(j + 2) * G::kTileBytes + st_goff[p]);
+                vst[p] = buf_load16(rv, (unsigned)(j + 2) * G::kTileBytes + st_goff[p]);
+            }
             if constexpr (kTrack) {
                 step_tracked(c0{}, j, sA, sB, pkB, pkA, so_0, so_m1, so_p2);
                 step_tracked(c1{}, j, sB, sA, pkA, pkB, so_p1, so_0, so_p2);
@@ -371,30 +403,33 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
                 for (int ks2 = 0; ks2 < 2; ++ks2) {
                     const u32x4 vf = read_vf(so, 1, db, ks2);
-                    o[0][db] = T::mfma32(vf, pkB[0][ks2], o[0][db]);
-                    o[1][db] = T::mfma32(vf, pkB[1][ks2], o[1][db]);
+#pragma unroll
+                    for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(vf, pkB[x][ks2], o[x][db]);
                 }
         }
     };
 
     run(no);
-    float l_row[2] = {l_part[0] + swap_halves(l_part[0]), l_part[1] + swap_halves(l_part[1])};
-    {
-        // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
-        const float lim = T::id == 1 ? INFINITY : 60000.0f;
-        const bool bad = !(l_row[0] < lim) || !(l_row[1] < lim);
-        if (__syncthreads_or(bad ? 1 : 0)) {
-            run(yes);
-            l_row[0] = l_part[0] + swap_halves(l_part[0]);
-            l_row[1] = l_part[1] + swap_halves(l_part[1]);
-        }
+    float l_row[X];
+    bool bad = false;
+    // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
+    const float lim = T::id == 1 ? INFINITY : 60000.0f;
+#pragma unroll
+    for (int x = 0; x < X; ++x) {
+        l_row[x] = l_part[x] + swap_halves(l_part[x]);
+        bad = bad || !(l_row[x] < lim);
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+        run(yes);
+#pragma unroll
+        for (int x = 0; x < X; ++x) l_row[x] = l_part[x] + swap_halves(l_part[x]);
     }
 
     constexpr unsigned es = kOutF32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t ro =
         make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < X; ++x) {
         const float inv = 1.0f / l_row[x];
         const unsigned row = q_row0 + 32u * x;
 #pragma unroll
@@ -416,12 +451,13 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, bool kOutF32>
+template <typename T, int D, int X, bool kOutF32>
 static hipError_t launch_w64p(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
-    using G = TileGeom<64>;
-    const int nqb = (N + w64p::kRows - 1) / w64p::kRows;
+    using G = TileGeom<D>;
+    constexpr int kRows = 32 * X * w64p::kW;
+    const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     static const int grid_cap = [] {
@@ -430,9 +466,9 @@ static hipError_t launch_w64p(const void* Q, const void* K, const void* V, void*
         return cus;
     }();
     const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
-    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64p_kernel<T, kOutF32>), w64p::kSlots * G::kBufBytes);
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64p_kernel<T, D, X, kOutF32>), w64p::kSlots * G::kBufBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fa_fwd_w64p_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64p::kW),
+    hipLaunchKernelGGL((fa_fwd_w64p_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64p::kW),
                        w64p::kSlots * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
@@ -443,13 +479,20 @@ hipError_t w64p_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream)
 {
-    if (D != 64) return hipErrorInvalidValue;
-    if ((unsigned long long)(N + w64p::kRows + 3 * kBlockN) * 64ull * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * w64p::kW + 3 * kBlockN) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D == 64) {
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_w64p<F16, 64, 2, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64p<F16, 64, 2, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64p<BF16, 64, 2, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64p<BF16, 64, 2, false>(Q, K, V, O, BH, N, scale, stream);
+    }
     if (in_dtype == 0)
-        return out_dtype == 0 ? launch_w64p<F16, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64p<F16, false>(Q, K, V, O, BH, N, scale, stream);
-    return out_dtype == 0 ? launch_w64p<BF16, true>(Q, K, V, O, BH, N, scale, stream)
-                          : launch_w64p<BF16, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64p<F16, 128, 1, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64p<F16, 128, 1, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_w64p<BF16, 128, 1, true>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_w64p<BF16, 128, 1, false>(Q, K, V, O, BH, N, scale, stream);
 }
 
 }  // namespace fa
