@@ -153,10 +153,11 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
 
         // ---- S^T = K.Q^T (raw fp32 scores) ------------------------------------------------
         f32x16 s[2];
+        // consecutive MFMAs alternate accumulators (a dependent MFMA issued right behind its producer stalls)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int ks = 0; ks < G::kKSteps; ++ks) {
 #pragma unroll
-            for (int ks = 0; ks < G::kKSteps; ++ks) {
+            for (int kb = 0; kb < 2; ++kb) {
                 const u32x4 kf = lds_read16(kbuf, kb * 32u * G::kRowBytes + k_rd_row +
                                                       (((2u * ks + h) ^ k_rd_swz) << 4));
                 s[kb] = T::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[kb]);
@@ -236,9 +237,9 @@ void fa_fwd_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__
 
         // ---- O^T += V^T.P^T -------------------------------------------------------------------
 #pragma unroll
-        for (int db = 0; db < G::kDBlocks; ++db) {
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int db = 0; db < G::kDBlocks; ++db) {
                 u32x4 vf;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {

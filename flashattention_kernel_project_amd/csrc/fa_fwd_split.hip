@@ -134,9 +134,9 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
         if (has_rows) {
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int ks = 0; ks < G::kKSteps; ++ks)   // consecutive MFMAs alternate accumulators
 #pragma unroll
-            for (int ks = 0; ks < G::kKSteps; ++ks) {
+            for (int kb = 0; kb < 2; ++kb) {
                 const u32x4 kf = lds_read16(kbuf, kb * 32u * G::kRowBytes + k_rd_row + (((2u * ks + h) ^ k_rd_swz) << 4));
                 s[kb] = T::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[kb]);
             }
@@ -184,9 +184,9 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
         l_part += ls0 + ls1;
 
 #pragma unroll
-        for (int db = 0; db < G::kDBlocks; ++db)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int db = 0; db < G::kDBlocks; ++db) {
                 u32x4 vf;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
