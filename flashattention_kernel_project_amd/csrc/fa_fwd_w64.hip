@@ -41,6 +41,9 @@ __device__ __forceinline__ void sfor(F&& f) {
 #ifndef FA_W64_KV_AUX
 #define FA_W64_KV_AUX 0   // cache-policy bits of the K/V staging loads (1 sc0, 2 nt, 16 sc1)
 #endif
+#ifndef FA_W64_FENCE
+#define FA_W64_FENCE 0   // 1: scheduling fence after every {MFMAs of a fragment; read of the fragment kAhead further}
+#endif
 #ifndef FA_W64_ALT
 #define FA_W64_ALT 1   // 1: consecutive MFMAs alternate accumulators (-1.6 % d=64, -2.1 % d=128 against 0); (key blocks in QK^T, head-dim blocks in PV) instead of running each chain to its end
 #endif
@@ -221,6 +224,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
 #pragma unroll
                 for (int x = 0; x < X; ++x) s[x][kb] = T::mfma32(frag[f % kRing], qf[x][ks], ks == 0 ? zero16 : s[x][kb]);
                 read_k(std::integral_constant<int, f + kAhead>{});
+                if constexpr (FA_W64_FENCE) __builtin_amdgcn_sched_barrier(0);
             });
 
             if (partial && t + 1 == ntiles) {   // keys >= N -> -inf (p = 0)
@@ -329,6 +333,7 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
 #pragma unroll
                 for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(frag[f % kRing], pk[x][ks], o[x][db]);
                 read_v(std::integral_constant<int, f + kAhead>{});
+                if constexpr (FA_W64_FENCE) __builtin_amdgcn_sched_barrier(0);
             });
             if (sync) __syncthreads();
         }
