@@ -37,8 +37,9 @@ extern "C" {
 #define FA_ALGO_TLP3            9 /* simple per-wave stream, three 128-row workgroups per CU, D = 64 */
 #define FA_ALGO_IL16           11 /* 16 waves x 16 rows on v_mfma_f32_16x16x32, D = 64 */
 #define FA_ALGO_IL2X16         12 /* 8 waves x two 16-row blocks sharing K/V fragments, 16x16x32, D = 64 */
-#define FA_ALGO_W64            13 /* 64 query rows per wave, 512-row workgroups, phase-ordered stream, D = 64 */
-#define FA_ALGO_W64P           14 /* the same with a half-tile rolling pipeline, D = 64 */
+#define FA_ALGO_W64            13 /* 64 query rows per wave (d=64) / 32 (d=128), phase-ordered stream, persistent grid */
+#define FA_ALGO_W64P           14 /* the same with a half-tile rolling pipeline, D in {64,128} */
+#define FA_ALGO_W64M           15 /* W64 with QK^T one tile ahead, merged with PV into one matrix phase (slower; A/B only) */
 /* 7, 8, 10: experimental occupancy variants kept for A/B timing (fp16, d=64). */
 
 /* General-shape forward.  Replaces
