@@ -73,8 +73,8 @@ constexpr int kAhead = FA_W64_AHEAD;   // LDS fragment read-ahead
 // diagonal, a wave skips (but still stages and synchronises) tiles wholly above its rows, crossed
 // tiles get the element mask.  Launched one workgroup per item, query blocks last-to-first within a
 // head, so the hardware dispatcher balances the unequal items.
-template <typename T, int D, int X, bool kOutF32, bool kCausal = false>
-__global__ __launch_bounds__(64 * w64::kW, 2)
+template <typename T, int D, int X, bool kOutF32, bool kCausal = false, int kW = w64::kW>
+__global__ __launch_bounds__(64 * kW, 2)
 void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                        const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                        int N, int nqb, float scale_log2e, unsigned total_wg)
@@ -384,12 +384,12 @@ void fa_fwd_w64_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restri
     }   // persistent loop over work items
 }
 
-template <typename T, int D, int X, bool kOutF32, bool kCausal = false>
+template <typename T, int D, int X, bool kOutF32, bool kCausal = false, int kW = w64::kW>
 static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* O,
                              int BH, int N, float scale, hipStream_t stream)
 {
     using G = TileGeom<D>;
-    constexpr int kRows = 32 * X * w64::kW;
+    constexpr int kRows = 32 * X * kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
@@ -398,12 +398,12 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
     }();
-    const long long cap = (long long)grid_cap * (8 / w64::kW);
+    const long long cap = (long long)grid_cap * (8 / kW);
     const unsigned grid = (nwg > cap && !kCausal) ? (unsigned)cap : (unsigned)nwg;
-    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>),
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal, kW>),
                                            2 * FA_W64_BARRIER_EVERY * G::kBufBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal>), dim3(grid), dim3(64 * w64::kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
+    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal, kW>), dim3(grid), dim3(64 * kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();
@@ -420,11 +420,12 @@ static hipError_t w64_dispatch_impl(const void* Q, const void* K, const void* V,
         // under the mask: one 32-row block per wave (256-row workgroups): twice the items to balance, a
         // finer diagonal, and no spills (the two-block causal instantiation is 12 VGPRs over budget)
         constexpr int X = kCausal ? 1 : 2;
+        constexpr int W = kCausal ? 4 : w64::kW;   // under the mask also 4 waves: 128-row workgroups, two per CU
         if (in_dtype == 0)
-            return out_dtype == 0 ? launch_w64<F16, 64, X, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_w64<F16, 64, X, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
-        return out_dtype == 0 ? launch_w64<BF16, 64, X, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64<BF16, 64, X, false, kCausal>(Q, K, V, O, BH, N, scale, stream);
+            return out_dtype == 0 ? launch_w64<F16, 64, X, true, kCausal, W>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64<F16, 64, X, false, kCausal, W>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64<BF16, 64, X, true, kCausal, W>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64<BF16, 64, X, false, kCausal, W>(Q, K, V, O, BH, N, scale, stream);
     }
     if (in_dtype == 0)
         return out_dtype == 0 ? launch_w64<F16, 128, 1, true, kCausal>(Q, K, V, O, BH, N, scale, stream)
