@@ -35,8 +35,11 @@ template <int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
+#ifndef FA_W64M_AHEAD
+#define FA_W64M_AHEAD 2
+#endif
 constexpr int kW = 8;
-constexpr int kAhead = 2, kRing = kAhead + 1;
+constexpr int kAhead = FA_W64M_AHEAD, kRing = kAhead + 1;
 }  // namespace w64m
 
 template <typename T, int D, int X, bool kOutF32>
