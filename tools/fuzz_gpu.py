@@ -37,6 +37,7 @@ def main():
     plain = {64: (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14), 128: (0, 1, 2, 4, 13)}
     caus = {64: (0, 1, 2, 6, 13), 128: (0, 1, 2, 6, 13)}
     t0, cases, fails, worst = time.time(), 0, 0, 0.0
+    next_note = t0 + 60.0
     while time.time() - t0 < args.seconds:
         kind = rng.choice(["plain", "plain", "causal", "split"])
         d = rng.choice([16, 32, 64, 64, 64, 128, 128, 256]) if kind != "split" else rng.choice([64, 128])
@@ -83,6 +84,9 @@ def main():
         if dt == torch.bfloat16 and kind != "split" and algo in (3, 4, 9, 10, 11, 12):
             tol += vmax * 2.0 ** -9
         cases += 1
+        if time.time() >= next_note:   # a silent GPU job is taken to be hung
+            print(f"... {cases} cases, {fails} failures so far", flush=True)
+            next_note += 60.0
         worst = max(worst, err)
         if not (err <= tol) or not torch.isfinite(got).all():
             fails += 1
