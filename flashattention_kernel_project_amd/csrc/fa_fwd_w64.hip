@@ -419,8 +419,11 @@ static hipError_t w64_dispatch_impl(const void* Q, const void* K, const void* V,
     if (D == 64) {
         // under the mask: one 32-row block per wave (256-row workgroups): twice the items to balance, a
         // finer diagonal, and no spills (the two-block causal instantiation is 12 VGPRs over budget)
-        constexpr int X = kCausal ? 1 : 2;
-        constexpr int W = kCausal ? 4 : w64::kW;   // under the mask also 4 waves: 128-row workgroups, two per CU
+#ifndef FA_W64_SMALL
+#define FA_W64_SMALL 0   // experiment: the 128-row (X = 1, 4 waves) shape without the mask, for small grids
+#endif
+        constexpr int X = (kCausal || FA_W64_SMALL) ? 1 : 2;
+        constexpr int W = (kCausal || FA_W64_SMALL) ? 4 : w64::kW;   // under the mask also 4 waves: 128-row workgroups, two per CU
         if (in_dtype == 0)
             return out_dtype == 0 ? launch_w64<F16, 64, X, true, kCausal, W>(Q, K, V, O, BH, N, scale, stream)
                                   : launch_w64<F16, 64, X, false, kCausal, W>(Q, K, V, O, BH, N, scale, stream);
