@@ -19,8 +19,13 @@
 // handful of query rows most MFMA work is idle lanes -- irrelevant here, the path is HBM-bound.
 #include "fa_tile.hpp"
 
+#include <cstdlib>
+
 namespace fa {
 
+#ifndef FA_SPLIT_ROTATE
+#define FA_SPLIT_ROTATE 1
+#endif
 #ifndef FA_SPLIT_NT
 #define FA_SPLIT_NT 1   // K/V are read exactly once: non-temporal loads (5.97 -> 6.75 TB/s at B8 H16 Nq1 Nk32768 d128)
 #endif
@@ -120,15 +125,20 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
     float m_ref = 0.0f, l_part = 0.0f;
 
     const int ntiles = (int)((key1 - key0 + kBlockN - 1) / kBlockN);   // >= 1 by construction of S
-    stage_load(key0);
+    // Tiles are visited in a rotated order that differs per (head, split): the chunks of one head start a
+    // power-of-two stride apart, and workgroups marching through them in lockstep would keep hitting the
+    // same few HBM channels.  The streaming softmax does not care about the order.
+    const unsigned rot = FA_SPLIT_ROTATE ? (sp * 5u + bh * 3u) % (unsigned)ntiles : 0u;
+    auto tile_of = [&](int t) { const unsigned ti = (unsigned)t + rot; return ti >= (unsigned)ntiles ? ti - (unsigned)ntiles : ti; };
+    stage_load(key0 + tile_of(0) * kBlockN);
     stage_write(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const unsigned cur = t & 1u;
         const char* kbuf = smem + cur * G::kBufBytes;
-        const unsigned kv0 = key0 + (unsigned)t * kBlockN;
-        if (t + 1 < ntiles) stage_load(kv0 + kBlockN);
+        const unsigned kv0 = key0 + tile_of(t) * kBlockN;
+        if (t + 1 < ntiles) stage_load(key0 + tile_of(t + 1) * kBlockN);
 
         // a wave whose 32 rows all lie past Nq (the usual case for a handful of query rows) only stages
         if (has_rows) {
@@ -244,31 +254,47 @@ void fa_fwd_split_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __rest
     }
 }
 
-// One thread per (bh, row, 4 output columns).
+// One wave per (bh, row).  Lane = (slice, 4 output columns): the D/4 column groups times 64/(D/4) slices of
+// the split axis, so that the S partials of a row are read by parallel lanes with independent loads instead
+// of one lane walking them (a serial walk costs ~0.25 us per partial: 64 us at S = 128).
 template <typename T, bool kOutF32>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64)
 void fa_split_combine_kernel(const float* __restrict__ ws, void* __restrict__ Og, int BH, int Nq, int D, int S)
 {
-    const int cols4 = D / 4;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)BH * Nq * cols4;
-    if (idx >= total) return;
-    const int c4 = (int)(idx % cols4);
-    const long long rowi = idx / cols4;
+    const int cols4 = D / 4;             // 16 or 32
+    const int nsl = 64 / cols4;          // 4 or 2 slices of the split axis
+    const unsigned lane = threadIdx.x;
+    const int c4 = (int)lane % cols4, sl = (int)lane / cols4;
+    const long long rowi = blockIdx.x;   // bh * Nq + row
     const int row = (int)(rowi % Nq);
     const int bh = (int)(rowi / Nq);
     const size_t stride_s = (size_t)Nq * (D + 2);
     const float* base = ws + (size_t)bh * S * stride_s + (size_t)row * (D + 2);
+    // global reference max: every lane takes splits lane, lane+64, ...
     float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, base[s * stride_s + D]);
+    for (int s = (int)lane; s < S; s += 64) M = fmaxf(M, base[(size_t)s * stride_s + D]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
     float L = 0.0f, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < S; ++s) {
-        const float* p = base + s * stride_s;
+#pragma unroll 4
+    for (int s = sl; s < S; s += nsl) {
+        const float* p = base + (size_t)s * stride_s;
         const float w = fast_exp2(p[D] - M);
         L += p[D + 1] * w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += p[4 * c4 + i] * w;
+        // workspace rows are (D+2)*4 bytes: 8-byte aligned, so two 8-byte loads
+        const float2 v0 = *reinterpret_cast<const float2*>(p + 4 * c4), v1 = *reinterpret_cast<const float2*>(p + 4 * c4 + 2);
+        acc[0] += v0.x * w;
+        acc[1] += v0.y * w;
+        acc[2] += v1.x * w;
+        acc[3] += v1.y * w;
     }
+    // sum the slices: lanes that differ only in `sl` are cols4, 2*cols4, ... apart
+    for (int o = cols4; o < 64; o <<= 1) {
+        L += __shfl_xor(L, o, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    if (sl != 0) return;
     const float inv = 1.0f / L;
     const size_t off = ((size_t)bh * Nq + row) * D + 4 * c4;
     if constexpr (kOutF32) {
@@ -288,8 +314,11 @@ int split_count(int BH, int Nq, int Nk)
 {
     const long long base = (long long)BH * ((Nq + split::kRows - 1) / split::kRows);
     const int tiles = (Nk + kBlockN - 1) / kBlockN;
-    long long s = (1024 + base - 1) / base;   // about four workgroups per CU
-    if (s > tiles / 4) s = tiles / 4;
+    // experiments: FA_SPLIT_TARGET workgroups in total, at least FA_SPLIT_MIN_TILES tiles per split
+    static const int target = [] { const char* v = getenv("FA_SPLIT_TARGET"); return v ? atoi(v) : 1024; }();
+    static const int min_tiles = [] { const char* v = getenv("FA_SPLIT_MIN_TILES"); return v ? atoi(v) : 4; }();
+    long long s = (target + base - 1) / base;   // about four workgroups per CU
+    if (s > tiles / min_tiles) s = tiles / min_tiles;
     if (s < 1) s = 1;
     // every split must hold at least one key: chunk = ceil(tiles / s) tiles, recompute s from the chunk
     const int chunk_tiles = (int)((tiles + s - 1) / s);
@@ -327,8 +356,9 @@ static hipError_t launch_split(const void* Q, const void* K, const void* V, void
                        stream, q, k, v, O, static_cast<float*>(ws), Nq, Nk, nqb, S, chunk, scale * kLog2e);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long long threads = (long long)BH * Nq * (D / 4);
-    hipLaunchKernelGGL((fa_split_combine_kernel<T, kOutF32>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+    const long long rows = (long long)BH * Nq;   // one wave per output row
+    if (rows > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((fa_split_combine_kernel<T, kOutF32>), dim3((unsigned)rows), dim3(64), 0, stream,
                        static_cast<const float*>(ws), O, BH, Nq, D, S);
     return hipGetLastError();
 }
