@@ -18,6 +18,8 @@
 #ifndef FA_MI355_H
 #define FA_MI355_H
 
+#include <stddef.h>   /* size_t (split-KV workspace) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
