@@ -106,3 +106,12 @@ def test_torch_custom_op_registers(fa):
     with pytest.raises(Exception):   # no CPU implementation: the product path is the HIP library only
         c = torch.zeros(1, 1, 16, 64, dtype=torch.float16)
         torch.ops.fa_mi355.forward(c, c, c, 0.125, False, True)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fa_mi355.h must compile as C99 on its own (the drop-in boundary is a C ABI)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "fa_mi355.h"\nint main(void) { return (int)sizeof(size_t) == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "hdr.o")])
