@@ -480,6 +480,9 @@ hipError_t w64p_dispatch(const void* Q, const void* K, const void* V, void* O,
 hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                         hipStream_t stream);
+hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
+                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
+                         hipStream_t stream);
 hipError_t w64m_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream);
@@ -523,6 +526,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 14) return w64p_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 15) return w64m_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 11) return il16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
