@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 F16, BF16 = 0, 1
 OUT_F32, OUT_SAME = 0, 1
 ALGO_AUTO, ALGO_GENERIC, ALGO_TILED, ALGO_PIPE, ALGO_PINGPONG, ALGO_INTERLEAVED, ALGO_INTERLEAVED_2WG = 0, 1, 2, 3, 4, 5, 6
-ALGO_TLP3, ALGO_IL16, ALGO_IL2X16, ALGO_W64, ALGO_W64P, ALGO_W64M = 9, 11, 12, 13, 14, 15
+ALGO_TLP3, ALGO_IL16, ALGO_IL2X16, ALGO_W64, ALGO_W64P, ALGO_W64M, ALGO_W64X = 9, 11, 12, 13, 14, 15, 16
 
 # every symbol include/fa_mi355.h declares
 SYMBOLS = (

@@ -505,11 +505,11 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     if (algo == 0 && D == 64) {
-        // d = 64: 64 query rows per wave in 512-row workgroups (fa_fwd_w64.hip) when those fill the chip
+        // d = 64: 64 query rows per wave in 512-row workgroups, on 16x16x32 MFMAs (fa_fwd_w64x.hip), when those fill the chip
         // at least twice over; else the interleaved kernel with 256-row workgroups, or 128-row ones
         // (two per CU) for twice the parallelism.
         const long long nwg512 = (long long)BH * ((N + 511) / 512);
-        if (nwg512 >= 512) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+        if (nwg512 >= 512) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, nwg256 >= 512 ? 8 : 4, stream);
     }
