@@ -513,8 +513,8 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, nwg256 >= 512 ? 8 : 4, stream);
     }
-    // d = 128: the tiled stream with the optimistic pass, packed fma and a persistent grid (fa_fwd_w64.hip, X = 1)
-    if (algo == 0 && D == 128) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    // d = 128: the same stream with two 16-row blocks per wave (fa_fwd_w64x.hip; 256-row workgroups)
+    if (algo == 0 && D == 128) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 7 || algo == 8) {   // experimental occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out

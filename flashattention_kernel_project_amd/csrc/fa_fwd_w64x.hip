@@ -43,12 +43,12 @@ template <> struct Mx<BF16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
-constexpr int kW = 8, kX = 4;            // waves per workgroup, 16-row blocks per wave
-constexpr int kRows = 16 * kX * kW;      // 512 query rows per workgroup
+constexpr int kW = 8;                    // waves per workgroup
 constexpr int kAhead = 2, kRing = kAhead + 1;
 }  // namespace w64x
 
-template <typename T, bool kOutF32>
+// D = head dim (64 or 128); X = 16-row query blocks per wave (4 at D = 64: 64 rows; 2 at D = 128: 32 rows).
+template <typename T, int D, int X, bool kOutF32>
 __global__ __launch_bounds__(64 * w64x::kW, 2)
 void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -56,8 +56,12 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 {
     using namespace w64x;
     using M = Mx<T>;
-    constexpr int D = 64, X = kX;
-    constexpr unsigned kTile = kBlockN * D * 2;     // 8 KB: one K or V tile
+    using G = TileGeom<D>;
+    constexpr int kRows = 16 * X * kW;              // query rows per workgroup
+    constexpr int kKS = D / 32, kDB = D / 16;       // k-steps of QK^T, 16-column blocks of O^T
+    constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);
+    constexpr unsigned kRowB = D * 2;
+    constexpr unsigned kTile = kBlockN * D * 2;     // one K or V tile
     constexpr unsigned kBuf = 2 * kTile;            // [K tile][V tile]
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two buffers
 
@@ -70,17 +74,22 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const int ntiles = (N + kBlockN - 1) / kBlockN;
     const bool partial = (N % kBlockN) != 0;
 
-    // staging: thread -> one 16-B chunk of the K tile and one of the V tile
-    const unsigned srow = tid >> 3, sch = tid & 7u;
-    const unsigned st_goff = srow * 128u + sch * 16u;
-    const unsigned k_lds = srow * 128u + ((sch ^ ((srow >> 1) & 7u)) << 4);
-    const unsigned v_lds = kTile + ((srow >> 3) * 4u + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
-    // K reads (A operand of QK^T): lane (c16,g) reads row 16*kb + c16, chunk 4*ks + g
-    unsigned k_rd[2];
+    // staging: thread -> kLoads 16-B chunks of the K tile and of the V tile
+    unsigned st_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) k_rd[ks] = c16 * 128u + (((4u * ks + g) ^ ((c16 >> 1) & 7u)) << 4);
+    for (int p = 0; p < kLoads; ++p) {
+        const unsigned idx = tid + p * 64u * kW;
+        const unsigned srow = idx / G::kChunks, sch = idx % G::kChunks;
+        st_goff[p] = srow * kRowB + sch * 16u;
+        k_lds[p] = G::k_off(srow, sch);
+        v_lds[p] = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
+    }
+    // K reads (A operand of QK^T): lane (c16,g) reads row 16*kb + c16, chunk 4*ks + g (the swizzle of row 16kb+c16 is that of c16)
+    unsigned k_rd[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) k_rd[ks] = c16 * kRowB + (((4u * ks + g) ^ G::k_swz(c16)) << 4);
     // V^T reads (A operand of PV)
-    const unsigned v_rd = kTile + (g >> 1) * 1024u + ((4u * (g & 1u) + (c16 >> 2)) << 5) + (c16 & 3u) * 8u;
+    const unsigned v_rd = kTile + (g >> 1) * (unsigned)kDB * 256u + ((4u * (g & 1u) + (c16 >> 2)) << 5) + (c16 & 3u) * 8u;
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr float kHeadroom = 4.0f;
@@ -109,53 +118,62 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
     const unsigned q_row0 = qb * kRows + wave * (16u * X) + c16;   // row of block 0; block x is 16x rows further
 
-    u32x4 qf[X][2];   // B operand of QK^T: Q[row of block x][32*ks + 8*g .. +7]
+    u32x4 qf[X][kKS];   // B operand of QK^T: Q[row of block x][32*ks + 8*g .. +7]
 #pragma unroll
     for (int x = 0; x < X; ++x)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 raw = buf_load16(rq, (q_row0 + 16u * x) * 128u + (32u * ks + 8u * g) * 2u);
+        for (int ks = 0; ks < kKS; ++ks) {
+            u32x4 raw = buf_load16(rq, (q_row0 + 16u * x) * kRowB + (32u * ks + 8u * g) * 2u);
 #pragma unroll
             for (int w = 0; w < 4; ++w) raw[w] ^= q_flip;
             qf[x][ks] = raw;
         }
 
-    f32x4 o[X][4];
+    f32x4 o[X][kDB];
     float m_ref[X] = {}, l_part[X] = {};
-    u32x4 kst, vst;
+    u32x4 kst[kLoads], vst[kLoads];
 
     auto run = [&](auto track_c) __attribute__((always_inline)) {
         constexpr bool kTrack = decltype(track_c)::value;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[x][db] = zero4;
+            for (int db = 0; db < kDB; ++db) o[x][db] = zero4;
             l_part[x] = 0.0f;
         }
-        kst = buf_load16(rk, st_goff);
-        vst = buf_load16(rv, st_goff);
-        lds_write16(smem, k_lds, kst);
-        lds_write16(smem, v_lds, vst);
+#pragma unroll
+        for (int p = 0; p < kLoads; ++p) {
+            kst[p] = buf_load16(rk, st_goff[p]);
+            vst[p] = buf_load16(rv, st_goff[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < kLoads; ++p) {
+            lds_write16(smem, k_lds[p], kst[p]);
+            lds_write16(smem, v_lds[p], vst[p]);
+        }
         __syncthreads();
 
         for (int t = 0; t < ntiles; ++t) {
             const unsigned cur = ((unsigned)t & 1u) * kBuf, nxt = kBuf - cur;
             // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
-            kst = buf_load16(rk, (unsigned)(t + 1) * kTile + st_goff);
-            vst = buf_load16(rv, (unsigned)(t + 1) * kTile + st_goff);
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                kst[p] = buf_load16(rk, (unsigned)(t + 1) * kTile + st_goff[p]);
+                vst[p] = buf_load16(rv, (unsigned)(t + 1) * kTile + st_goff[p]);
+            }
 
-            // ---- S^T = K.Q^T: 8 K fragments (key block kb, k-step ks), each feeding the four query blocks --------
+            // ---- S^T = K.Q^T: 4*kKS K fragments (key block kb, k-step ks), each feeding the X query blocks --------
             f32x4 s[X][4];
             u32x4 frag[kRing];
             auto read_k = [&](auto fc) {
                 constexpr int f = decltype(fc)::value;
-                if constexpr (f < 8) {
+                if constexpr (f < 4 * kKS) {
                     constexpr int kb = f % 4, ks = f / 4;
-                    frag[f % kRing] = lds_read16(smem, cur + kb * 16u * 128u + k_rd[ks]);
+                    frag[f % kRing] = lds_read16(smem, cur + kb * 16u * kRowB + k_rd[ks]);
                 }
             };
             sfor<kAhead>([&](auto fc) { read_k(fc); });
-            sfor<8>([&](auto fc) {
+            sfor<4 * kKS>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, kb = f % 4, ks = f / 4;
 #pragma unroll
                 for (int x = 0; x < X; ++x) s[x][kb] = M::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? zero4 : s[x][kb]);
@@ -186,7 +204,7 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                         const float alpha = fast_exp2(m_ref[x] - m_new);
                         m_ref[x] = m_new;
 #pragma unroll
-                        for (int db = 0; db < 4; ++db)
+                        for (int db = 0; db < kDB; ++db)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) o[x][db][i] *= alpha;
                         l_part[x] *= alpha;
@@ -215,15 +233,15 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 l_part[x] += ls0 + ls1;
             }
 
-            // ---- O^T += V^T.P^T: 8 V^T fragments (k-step sk, head-dim block db), each feeding the four blocks -------
+            // ---- O^T += V^T.P^T: 2*kDB V^T fragments (k-step sk, head-dim block db), each feeding the X blocks -------
             auto read_v = [&](auto fc) {
                 constexpr int f = decltype(fc)::value;
-                if constexpr (f < 8) {
-                    constexpr int db = f % 4, sk = f / 4;
+                if constexpr (f < 2 * kDB) {
+                    constexpr int db = f % kDB, sk = f / kDB;
                     u32x4 vf;
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        const u32x2 half = lds_read_tr8(smem, cur + v_rd + (4u * sk + 2u * jj) * 1024u + db * 256u);
+                        const u32x2 half = lds_read_tr8(smem, cur + v_rd + (4u * sk + 2u * jj) * (unsigned)kDB * 256u + db * 256u);
                         vf[2 * jj] = half[0];
                         vf[2 * jj + 1] = half[1];
                     }
@@ -231,11 +249,14 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 }
             };
             sfor<kAhead>([&](auto fc) { read_v(fc); });
-            sfor<8>([&](auto fc) {
-                constexpr int f = decltype(fc)::value, db = f % 4, sk = f / 4;
-                if constexpr (f == 4) {   // land the next tile in the other buffer (half way through PV)
-                    lds_write16(smem, nxt + k_lds, kst);
-                    lds_write16(smem, nxt + v_lds, vst);
+            sfor<2 * kDB>([&](auto fc) {
+                constexpr int f = decltype(fc)::value, db = f % kDB, sk = f / kDB;
+                if constexpr (f == kDB) {   // land the next tile in the other buffer (half way through PV)
+#pragma unroll
+                    for (int p = 0; p < kLoads; ++p) {
+                        lds_write16(smem, nxt + k_lds[p], kst[p]);
+                        lds_write16(smem, nxt + v_lds[p], vst[p]);
+                    }
                 }
 #pragma unroll
                 for (int x = 0; x < X; ++x) o[x][db] = M::mfma(frag[f % kRing], pk[x][sk], o[x][db]);
@@ -269,7 +290,7 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         const float inv = 1.0f / l_row[x];
         const unsigned row = q_row0 + 16u * x;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < kDB; ++db) {
             const unsigned col = 16u * db + 4u * g;
             const float a = o[x][db][0] * inv, b = o[x][db][1] * inv, cc = o[x][db][2] * inv, d = o[x][db][3] * inv;
             if constexpr (kOutF32) {
@@ -283,12 +304,13 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, bool kOutF32>
+template <typename T, int D, int X, bool kOutF32>
 static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
-    constexpr int lds_bytes = 4 * kBlockN * 64 * 2;   // 32 KB: two [K tile][V tile] buffers
-    const int nqb = (N + w64x::kRows - 1) / w64x::kRows;
+    constexpr int lds_bytes = 4 * kBlockN * D * 2;   // two [K tile][V tile] buffers: 32 KB (d=64), 64 KB (d=128)
+    constexpr int kRows = 16 * X * w64x::kW;
+    const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     static const int grid_cap = [] {
@@ -297,23 +319,36 @@ static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void*
         return cus;
     }();
     const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
-    hipLaunchKernelGGL((fa_fwd_w64x_kernel<T, kOutF32>), dim3(grid), dim3(64 * w64x::kW), lds_bytes, stream,
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64x_kernel<T, D, X, kOutF32>), lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((fa_fwd_w64x_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64x::kW), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();
 }
 
+#ifndef FA_W64X_X128
+#define FA_W64X_X128 2   // 16-row blocks per wave at d = 128
+#endif
+
 hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream)
 {
-    if (D != 64) return hipErrorInvalidValue;
-    if ((unsigned long long)(N + w64x::kRows) * 64ull * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * w64x::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (D == 64) {
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_w64x<F16, 64, 4, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64x<F16, 64, 4, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64x<BF16, 64, 4, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64x<BF16, 64, 4, false>(Q, K, V, O, BH, N, scale, stream);
+    }
     if (in_dtype == 0)
-        return out_dtype == 0 ? launch_w64x<F16, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64x<F16, false>(Q, K, V, O, BH, N, scale, stream);
-    return out_dtype == 0 ? launch_w64x<BF16, true>(Q, K, V, O, BH, N, scale, stream)
-                          : launch_w64x<BF16, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64x<F16, 128, FA_W64X_X128, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64x<F16, 128, FA_W64X_X128, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_w64x<BF16, 128, FA_W64X_X128, true>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_w64x<BF16, 128, FA_W64X_X128, false>(Q, K, V, O, BH, N, scale, stream);
 }
 
 }  // namespace fa

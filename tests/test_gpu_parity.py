@@ -41,7 +41,7 @@ def _run(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False, scale=None):
 
 
 def _algos_for(d):
-    return (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16) if d == 64 else ((0, 1, 2, 4, 13, 14, 15) if d == 128 else (0, 1))
+    return (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16) if d == 64 else ((0, 1, 2, 4, 13, 14, 15, 16) if d == 128 else (0, 1))
 
 
 def _check(oracle, got, want, fmt, what, out_same=False, max_abs=MAX_ABS):

@@ -34,7 +34,7 @@ def main():
     import flashattention_kernel_project_amd as fa
     rng = random.Random(args.seed)
     g = torch.Generator(device="cuda").manual_seed(args.seed)
-    plain = {64: (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16), 128: (0, 1, 2, 4, 13, 14, 15)}
+    plain = {64: (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16), 128: (0, 1, 2, 4, 13, 14, 15, 16)}
     caus = {64: (0, 1, 2, 6, 13), 128: (0, 1, 2, 6, 13)}
     t0, cases, fails, worst = time.time(), 0, 0, 0.0
     next_note = t0 + 60.0
