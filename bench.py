@@ -116,7 +116,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4),
                          "traffic": measured_traffic(B, H, N, d, args.dtype, args.out),
-                         "kernel": "fa::fa_fwd_w64x_kernel" if d == 64 else ("fa::fa_fwd_w64_kernel" if d == 128 else "fa::fa_fwd_generic_kernel"), "avg_launch_ms": round(kern_ms, 5),
+                         "kernel": "fa::fa_fwd_w64x_kernel" if d in (64, 128) else "fa::fa_fwd_generic_kernel", "avg_launch_ms": round(kern_ms, 5),
                          "algorithmic_bytes": fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2),
                          "hbm_GBps_algorithmic": round(fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2)
                                                        / (kern_ms * 1e-3) / 1e9, 1)},

@@ -29,7 +29,7 @@ extern "C" {
 #define FA_OUT_F32    0   /* the reference's output type */
 #define FA_OUT_SAME   1   /* output in the input's 16-bit type */
 
-#define FA_ALGO_AUTO            0 /* d=64: W64X (INTERLEAVED / _2WG when the grid is small); d=128: W64; else GENERIC */
+#define FA_ALGO_AUTO            0 /* d=64: W64X (INTERLEAVED / _2WG when the grid is small); d=128: W64X; else GENERIC */
 #define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
 #define FA_ALGO_PIPE            3 /* the same with QK^T of tile t+1 under the softmax of tile t, D = 64 */
@@ -42,7 +42,7 @@ extern "C" {
 #define FA_ALGO_W64            13 /* 64 query rows per wave (d=64) / 32 (d=128), phase-ordered stream, persistent grid */
 #define FA_ALGO_W64P           14 /* the same with a half-tile rolling pipeline, D in {64,128} */
 #define FA_ALGO_W64M           15 /* W64 with QK^T one tile ahead, merged with PV into one matrix phase (slower; A/B only) */
-#define FA_ALGO_W64X           16 /* W64 at d=64 on v_mfma_f32_16x16x32: four 16-row blocks per wave share every fragment */
+#define FA_ALGO_W64X           16 /* the W64 stream on v_mfma_f32_16x16x32: four (d=64) / two (d=128) 16-row blocks per wave share every fragment */
 /* 7, 8, 10: experimental occupancy variants kept for A/B timing (fp16, d=64). */
 
 /* General-shape forward.  Replaces
