@@ -44,7 +44,13 @@ template <> struct Mx<BF16> {
     }
 };
 constexpr int kW = 8;                    // waves per workgroup
-constexpr int kAhead = 2, kRing = kAhead + 1;
+#ifndef FA_W64X_AHEAD
+#define FA_W64X_AHEAD 2
+#endif
+#ifndef FA_W64X_DOT2
+#define FA_W64X_DOT2 0   // fp16 row sums: 0 = v_add of the fp32 p (-3.7 % at d=64, -2.5 % at d=128 against 1 = v_dot2c over the rounded weights); bf16 always v_dot2c (accuracy)
+#endif
+constexpr int kAhead = FA_W64X_AHEAD, kRing = kAhead + 1;
 }  // namespace w64x
 
 // D = head dim (64 or 128); X = 16-row query blocks per wave (4 at D = 64: 64 rows; 2 at D = 128: 32 rows).
@@ -225,10 +231,16 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     for (int pr = 0; pr < 2; ++pr) {
                         f32x2 v = {s[x][kb][2 * pr], s[x][kb][2 * pr + 1]};
                         v = __builtin_elementwise_fma(v, c2, nm);
-                        const unsigned w = T::pack2(fast_exp2(v[0]), fast_exp2(v[1]));
+                        const float p0 = fast_exp2(v[0]), p1 = fast_exp2(v[1]);
+                        const unsigned w = T::pack2(p0, p1);
                         pk[x][kb >> 1][(kb & 1) * 2 + pr] = w;
-                        if (pr) ls1 = T::sum2(w, ls1);
-                        else ls0 = T::sum2(w, ls0);
+                        if constexpr (T::kSumRounded || FA_W64X_DOT2) {
+                            if (pr) ls1 = T::sum2(w, ls1);
+                            else ls0 = T::sum2(w, ls0);
+                        } else {
+                            ls0 += p0;
+                            ls1 += p1;
+                        }
                     }
                 l_part[x] += ls0 + ls1;
             }
