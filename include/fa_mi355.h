@@ -29,7 +29,7 @@ extern "C" {
 #define FA_OUT_F32    0   /* the reference's output type */
 #define FA_OUT_SAME   1   /* output in the input's 16-bit type */
 
-#define FA_ALGO_AUTO            0 /* d=64: W64X (INTERLEAVED / _2WG when the grid is small); d=128: W64X; else GENERIC */
+#define FA_ALGO_AUTO            0 /* d=64: W64X for fp16, W64 for bf16 (INTERLEAVED / _2WG when the grid is small); d=128: W64X; else GENERIC */
 #define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
 #define FA_ALGO_PIPE            3 /* the same with QK^T of tile t+1 under the softmax of tile t, D = 64 */
