@@ -509,7 +509,11 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
         // at least twice over; else the interleaved kernel with 256-row workgroups, or 128-row ones
         // (two per CU) for twice the parallelism.
         const long long nwg512 = (long long)BH * ((N + 511) / 512);
-        if (nwg512 >= 512) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+        // fp16 on 16x16x32 MFMAs (w64x), bf16 on 32x32x16 (w64): bf16 draws less power, holds a higher clock and is
+        // decided by cycle count (w64: 3 % fewer), fp16 by energy (w64x: -2...-5 % wall) -- measured on five devices
+        if (nwg512 >= 512)
+            return in_dtype == 0 ? w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream)
+                                 : w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, nwg256 >= 512 ? 8 : 4, stream);
     }
