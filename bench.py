@@ -28,8 +28,9 @@ PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults long enough for the clocks to settle: the first ~30 ms after idle run 5 % slower (50/10: 0.600 ms, 200/50: 0.569)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--H", type=int, default=16)
     ap.add_argument("--N", type=int, default=4096)
