@@ -43,7 +43,10 @@ template <> struct Mx<BF16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
-constexpr int kW = 8;                    // waves per workgroup
+#ifndef FA_W64X_WAVES
+#define FA_W64X_WAVES 8
+#endif
+constexpr int kW = FA_W64X_WAVES;        // waves per workgroup (4: two independent workgroups per CU)
 #ifndef FA_W64X_AHEAD
 #define FA_W64X_AHEAD 2
 #endif
@@ -330,7 +333,8 @@ static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void*
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus;
     }();
-    const unsigned grid = nwg > grid_cap ? (unsigned)grid_cap : (unsigned)nwg;
+    const long long cap = (long long)grid_cap * (8 / w64x::kW);
+    const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64x_kernel<T, D, X, kOutF32>), lds_bytes);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((fa_fwd_w64x_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64x::kW), lds_bytes, stream,
