@@ -50,6 +50,9 @@ constexpr int kW = FA_W64X_WAVES;        // waves per workgroup (4: two independ
 #ifndef FA_W64X_AHEAD
 #define FA_W64X_AHEAD 2
 #endif
+#ifndef FA_W64X_PKADD
+#define FA_W64X_PKADD 1   // fp16 row sums at d=64 by v_pk_add_f32, one instruction per pair (-1.8 % against two v_add; neutral at d=128: off there)
+#endif
 #ifndef FA_W64X_DOT2
 #define FA_W64X_DOT2 0   // fp16 row sums: 0 = v_add of the fp32 p (-3.7 % at d=64, -2.5 % at d=128 against 1 = v_dot2c over the rounded weights); bf16 always v_dot2c (accuracy)
 #endif
@@ -228,6 +231,7 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             for (int x = 0; x < X; ++x) {
                 const f32x2 nm = {-m_ref[x], -m_ref[x]};
                 float ls0 = 0.0f, ls1 = 0.0f;
+                f32x2 lsv = {0.0f, 0.0f}, lsw = {0.0f, 0.0f};
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -240,12 +244,16 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                         if constexpr (T::kSumRounded || FA_W64X_DOT2) {
                             if (pr) ls1 = T::sum2(w, ls1);
                             else ls0 = T::sum2(w, ls0);
+                        } else if constexpr (FA_W64X_PKADD && D == 64) {   // one v_pk_add_f32 per pair, two chains
+                            const f32x2 pv = {p0, p1};
+                            if (pr) lsw = lsw + pv;
+                            else lsv = lsv + pv;
                         } else {
                             ls0 += p0;
                             ls1 += p1;
                         }
                     }
-                l_part[x] += ls0 + ls1;
+                l_part[x] += (ls0 + ls1) + ((lsv[0] + lsv[1]) + (lsw[0] + lsw[1]));
             }
 
             // ---- O^T += V^T.P^T: 2*kDB V^T fragments (k-step sk, head-dim block db), each feeding the X blocks -------
