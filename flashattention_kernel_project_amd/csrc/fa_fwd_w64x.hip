@@ -50,6 +50,10 @@ constexpr int kW = FA_W64X_WAVES;        // waves per workgroup (4: two independ
 #ifndef FA_W64X_AHEAD
 #define FA_W64X_AHEAD 2
 #endif
+#ifndef FA_W64X_MIDBAR
+#define FA_W64X_MIDBAR 0   // 1: three K/V buffers, the one barrier per tile sits right behind the mid-PV staging write, and the
+                           // next tile's first K fragments are read during the second half of PV (no LDS latency, no barrier, at the tile boundary)
+#endif
 #ifndef FA_W64X_PKADD
 #define FA_W64X_PKADD 1   // fp16 row sums at d=64 by v_pk_add_f32, one instruction per pair (-1.8 % against two v_add; neutral at d=128: off there)
 #endif
@@ -164,9 +168,15 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             lds_write16(smem, v_lds[p], vst[p]);
         }
         __syncthreads();
+        u32x4 kpre[kAhead];   // FA_W64X_MIDBAR: the first K fragments of the next tile, read ahead of the tile boundary
+        if constexpr (FA_W64X_MIDBAR) {
+#pragma unroll
+            for (int i = 0; i < kAhead; ++i) kpre[i] = lds_read16(smem, (i % 4) * 16u * kRowB + k_rd[i / 4]);
+        }
+        unsigned cur = 0u;
 
         for (int t = 0; t < ntiles; ++t) {
-            const unsigned cur = ((unsigned)t & 1u) * kBuf, nxt = kBuf - cur;
+            const unsigned nxt = FA_W64X_MIDBAR ? (cur == 2u * kBuf ? 0u : cur + kBuf) : kBuf - cur;
             // next tile: tiles past the end read zeros through the buffer bounds, into the free buffer
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
@@ -184,7 +194,11 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     frag[f % kRing] = lds_read16(smem, cur + kb * 16u * kRowB + k_rd[ks]);
                 }
             };
-            sfor<kAhead>([&](auto fc) { read_k(fc); });
+            if constexpr (FA_W64X_MIDBAR) {
+                sfor<kAhead>([&](auto fc) { frag[decltype(fc)::value % kRing] = kpre[decltype(fc)::value]; });
+            } else {
+                sfor<kAhead>([&](auto fc) { read_k(fc); });
+            }
             sfor<4 * kKS>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, kb = f % 4, ks = f / 4;
 #pragma unroll
@@ -280,13 +294,20 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                         lds_write16(smem, nxt + k_lds[p], kst[p]);
                         lds_write16(smem, nxt + v_lds[p], vst[p]);
                     }
+                    if constexpr (FA_W64X_MIDBAR) {
+                        __syncthreads();   // tile t+1 visible; everybody is past tile t-1 (whose buffer tile t+2 will take)
+#pragma unroll
+                        for (int i = 0; i < kAhead; ++i) kpre[i] = lds_read16(smem, nxt + (i % 4) * 16u * kRowB + k_rd[i / 4]);
+                    }
                 }
 #pragma unroll
                 for (int x = 0; x < X; ++x) o[x][db] = M::mfma(frag[f % kRing], pk[x][sk], o[x][db]);
                 read_v(std::integral_constant<int, f + kAhead>{});
             });
-            __syncthreads();
+            if constexpr (!FA_W64X_MIDBAR) __syncthreads();
+            cur = nxt;
         }
+        if constexpr (FA_W64X_MIDBAR) __syncthreads();   // the buffers are rewritten by whatever runs next
     };
 
     run(no);
@@ -331,7 +352,7 @@ template <typename T, int D, int X, bool kOutF32>
 static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
-    constexpr int lds_bytes = 4 * kBlockN * D * 2;   // two [K tile][V tile] buffers: 32 KB (d=64), 64 KB (d=128)
+    constexpr int lds_bytes = (FA_W64X_MIDBAR ? 6 : 4) * kBlockN * D * 2;   // two (three) [K tile][V tile] buffers
     constexpr int kRows = 16 * X * w64x::kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
