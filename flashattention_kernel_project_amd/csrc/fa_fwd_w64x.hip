@@ -50,6 +50,9 @@ constexpr int kW = FA_W64X_WAVES;        // waves per workgroup (4: two independ
 #ifndef FA_W64X_AHEAD
 #define FA_W64X_AHEAD 2
 #endif
+#ifndef FA_W64X_STAGE_AT
+#define FA_W64X_STAGE_AT 2   // quarter of the PV phase in front of which the staged tile is written to LDS (0..3)
+#endif
 #ifndef FA_W64X_MIDBAR
 #define FA_W64X_MIDBAR 0   // 1: three K/V buffers, the one barrier per tile sits right behind the mid-PV staging write, and the
                            // next tile's first K fragments are read during the second half of PV (no LDS latency, no barrier, at the tile boundary)
@@ -288,7 +291,7 @@ void fa_fwd_w64x_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             sfor<kAhead>([&](auto fc) { read_v(fc); });
             sfor<2 * kDB>([&](auto fc) {
                 constexpr int f = decltype(fc)::value, db = f % kDB, sk = f / kDB;
-                if constexpr (f == kDB) {   // land the next tile in the other buffer (half way through PV)
+                if constexpr (f == (FA_W64X_STAGE_AT * 2 * kDB) / 4) {   // land the next tile in the other buffer (default: half way through PV)
 #pragma unroll
                     for (int p = 0; p < kLoads; ++p) {
                         lds_write16(smem, nxt + k_lds[p], kst[p]);
