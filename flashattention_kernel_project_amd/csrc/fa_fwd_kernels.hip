@@ -505,13 +505,15 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     if (algo == 0 && D == 64) {
-        // d = 64: 64 query rows per wave in 512-row workgroups, on 16x16x32 MFMAs (fa_fwd_w64x.hip), when those fill the chip
+        // d = 64: 64 query rows per wave in 512-row workgroups, on 16x16x32 MFMAs (fa_fwd_w64x.hip), when there is at least one per CU
         // at least twice over; else the interleaved kernel with 256-row workgroups, or 128-row ones
         // (two per CU) for twice the parallelism.
         const long long nwg512 = (long long)BH * ((N + 511) / 512);
         // fp16 on 16x16x32 MFMAs (w64x), bf16 on 32x32x16 (w64): bf16 draws less power, holds a higher clock and is
         // decided by cycle count (w64: 3 % fewer), fp16 by energy (w64x: -2...-5 % wall) -- measured on five devices
-        if (nwg512 >= 512)
+        // (one 512-row workgroup per CU is already enough: B2 H16 N4096 0.141 vs 0.150 ms, B4 H16 N2048 0.083 vs 0.086 for the
+        // interleaved kernel; at half a workgroup per CU -- B1 H16 N4096 -- the smaller workgroups win 0.088 vs 0.141)
+        if (nwg512 >= 256)
             return in_dtype == 0 ? w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream)
                                  : w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
