@@ -375,6 +375,9 @@ static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void*
     return hipGetLastError();
 }
 
+#ifndef FA_W64X_X64
+#define FA_W64X_X64 4    // 16-row blocks per wave at d = 64
+#endif
 #ifndef FA_W64X_X128
 #define FA_W64X_X128 2   // 16-row blocks per wave at d = 128
 #endif
@@ -387,10 +390,10 @@ hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
     if ((unsigned long long)(N + 64 * w64x::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (D == 64) {
         if (in_dtype == 0)
-            return out_dtype == 0 ? launch_w64x<F16, 64, 4, true>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_w64x<F16, 64, 4, false>(Q, K, V, O, BH, N, scale, stream);
-        return out_dtype == 0 ? launch_w64x<BF16, 64, 4, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_w64x<BF16, 64, 4, false>(Q, K, V, O, BH, N, scale, stream);
+            return out_dtype == 0 ? launch_w64x<F16, 64, FA_W64X_X64, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_w64x<F16, 64, FA_W64X_X64, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_w64x<BF16, 64, FA_W64X_X64, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_w64x<BF16, 64, FA_W64X_X64, false>(Q, K, V, O, BH, N, scale, stream);
     }
     if (in_dtype == 0)
         return out_dtype == 0 ? launch_w64x<F16, 128, FA_W64X_X128, true>(Q, K, V, O, BH, N, scale, stream)
