@@ -26,6 +26,7 @@ SYMBOLS = (
     "flashattn_streaming_16x16_mw",
     "flashattn_streaming_16x16_mw_kt",
     "fa_mi355_version",
+    "fa_mi355_has_experiments",
 )
 
 
@@ -83,8 +84,10 @@ def lib() -> C.CDLL:
         L.fa_debug_stage.argtypes = [i, vp, vp, vp, i, i, i, f, i, vp]
         L.flashattn_streaming_16x16_mw.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         L.flashattn_streaming_16x16_mw_kt.argtypes = [vp, vp, vp, vp, i, i, f, vp]
-        for s in SYMBOLS[:-1]:
+        for s in SYMBOLS[:-2]:
             getattr(L, s).restype = C.c_int
+        L.fa_mi355_has_experiments.argtypes = []
+        L.fa_mi355_has_experiments.restype = C.c_int
         L.fa_forward_splitkv_workspace_bytes.restype = C.c_size_t
         L.fa_mi355_version.argtypes = []
         L.fa_mi355_version.restype = C.c_char_p

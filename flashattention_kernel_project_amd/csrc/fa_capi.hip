@@ -17,54 +17,91 @@ hipError_t debug_stage_dispatch(int stage, const void* A, const void* B, void* O
 hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
                                 int num_batches, int seq_len, float scale, bool k_transposed,
                                 hipStream_t stream);
+#ifdef FA_EXPERIMENTS
 hipError_t pp_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, float scale, unsigned long long* diag, int mode, hipStream_t stream);
 hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream);
+hipError_t sk_diag_dispatch(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale, int variant,
+                            unsigned long long* diag, hipStream_t stream);
+hipError_t lab_w64x_dispatch(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale,
+                             int kstruct, int abl, unsigned long long* diag, hipStream_t stream);
+#endif
 }  // namespace fa
+
+// The library is built with -fvisibility=hidden: only the entry points below leave it.
+#define FA_EXPORT __attribute__((visibility("default")))
 
 extern "C" {
 
-// Diagnostic only (not in the public header): compute / stage-wait / barrier time of the interleaved kernel.
-int fa_debug_il_times(const void* Q, const void* K, const void* V, void* O,
+#ifdef FA_EXPERIMENTS
+// ---- libfa_mi355_exp.so only (make experimental): measurement entry points, not in the public header ----
+// fa_fwd_w64x stream, instantiated per experiment (fa_lab_w64x.hip): kstruct 0 shipped order, 1 two half-iterations
+// per tile, 3 the same with waves 4-7 half an iteration behind; abl = timing-ablation bits; diag = per-phase stamps.
+FA_EXPORT int fa_lab_w64x(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale,
+                int kstruct, int abl, unsigned long long* diag, void* stream)
+{
+    return (int)fa::lab_w64x_dispatch(Q, K, V, O, BH, N, scale, kstruct, abl, diag, static_cast<hipStream_t>(stream));
+}
+
+// fa_fwd_sk (fp16 -> fp32, d = 64) with per-phase s_memtime stamps: diag[wg][wave][8]; variant 0 shipped, 1 no fold, 2 no skew, 3 neither
+FA_EXPORT int fa_lab_sk(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale, int variant,
+              unsigned long long* diag, void* stream)
+{
+    return (int)fa::sk_diag_dispatch(Q, K, V, O, BH, N, scale, variant, diag, static_cast<hipStream_t>(stream));
+}
+
+// compute / stage-wait / barrier time of the interleaved kernel.
+FA_EXPORT int fa_debug_il_times(const void* Q, const void* K, const void* V, void* O,
                       int BH, int N, float scale, unsigned long long* diag, int waves, void* stream)
 {
     return (int)fa::il_diag_dispatch(Q, K, V, O, BH, N, scale, diag, waves, static_cast<hipStream_t>(stream));
 }
 
-// Diagnostic only (not declared in the public header): phase-time stamps of the ping-pong kernel.
-int fa_debug_pp_phase_times(const void* Q, const void* K, const void* V, void* O,
+// phase-time stamps of the ping-pong kernel.
+FA_EXPORT int fa_debug_pp_phase_times(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, float scale, unsigned long long* diag, int mode, void* stream)
 {
     return (int)fa::pp_diag_dispatch(Q, K, V, O, BH, N, scale, diag, mode, static_cast<hipStream_t>(stream));
 }
+#endif  // FA_EXPERIMENTS
 
-int flashattn_forward_wmma(const void* Q, const void* K, const void* V, float* O,
+// 1 when this build carries the experimental A/B kernels (explicit algo ids 3, 4, 7-12, 14, 15), else 0.
+FA_EXPORT int fa_mi355_has_experiments(void)
+{
+#ifdef FA_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+FA_EXPORT int flashattn_forward_wmma(const void* Q, const void* K, const void* V, float* O,
                            int BH, int N, int D, float scale, void* stream)
 {
     return (int)fa::forward_dispatch(Q, K, V, O, BH, N, D, scale, FA_DTYPE_F16, FA_OUT_F32, FA_ALGO_AUTO,
                                      static_cast<hipStream_t>(stream));
 }
 
-int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
+FA_EXPORT int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
                   int B, int H, int N, int d, float scale,
                   int in_dtype, int out_dtype, int algo, void* stream)
 {
     if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
-    if (algo < FA_ALGO_AUTO || algo > 16) return (int)hipErrorInvalidValue;
+    if (algo < FA_ALGO_AUTO || algo > 22) return (int)hipErrorInvalidValue;
     if (out_dtype != FA_OUT_F32 && out_dtype != FA_OUT_SAME) return (int)hipErrorInvalidValue;
     return (int)fa::forward_dispatch(Q, K, V, O, B * H, N, d, scale, in_dtype, out_dtype, algo,
                                      static_cast<hipStream_t>(stream));
 }
 
-int fa_forward(const void* Q, const void* K, const void* V, void* O,
+FA_EXPORT int fa_forward(const void* Q, const void* K, const void* V, void* O,
                int B, int H, int N, int d, float scale,
                int in_dtype, int out_dtype, void* stream)
 {
     return fa_forward_ex(Q, K, V, O, B, H, N, d, scale, in_dtype, out_dtype, FA_ALGO_AUTO, stream);
 }
 
-int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
+FA_EXPORT int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                       int B, int H, int N, int d, float scale,
                       int in_dtype, int out_dtype, int algo, void* stream)
 {
@@ -74,13 +111,13 @@ int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                                             static_cast<hipStream_t>(stream));
 }
 
-size_t fa_forward_splitkv_workspace_bytes(int B, int H, int Nq, int Nk, int d)
+FA_EXPORT size_t fa_forward_splitkv_workspace_bytes(int B, int H, int Nq, int Nk, int d)
 {
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || (long long)B * H > 0x7FFFFFFFll) return 0;
     return fa::split_workspace_bytes(B * H, Nq, Nk, d);
 }
 
-int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
+FA_EXPORT int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
                        int B, int H, int Nq, int Nk, int d, float scale,
                        int in_dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream)
 {
@@ -89,26 +126,26 @@ int fa_forward_splitkv(const void* Q, const void* K, const void* V, void* O,
                                    static_cast<hipStream_t>(stream));
 }
 
-int fa_debug_stage(int stage, const void* A, const void* B, void* Out, int BH, int N, int d, float scale,
+FA_EXPORT int fa_debug_stage(int stage, const void* A, const void* B, void* Out, int BH, int N, int d, float scale,
                    int dtype, void* stream)
 {
     return (int)fa::debug_stage_dispatch(stage, A, B, Out, BH, N, d, scale, dtype, static_cast<hipStream_t>(stream));
 }
 
-int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,
+FA_EXPORT int flashattn_streaming_16x16_mw(const void* Q, const void* K, const void* V, float* O,
                                  int num_batches, int seq_len, float scale, void* stream)
 {
     return (int)fa::streaming16_dispatch(Q, K, V, O, num_batches, seq_len, scale, false,
                                          static_cast<hipStream_t>(stream));
 }
 
-int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, const void* V, float* O,
+FA_EXPORT int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, const void* V, float* O,
                                     int num_batches, int seq_len, float scale, void* stream)
 {
     return (int)fa::streaming16_dispatch(Q, K_T, V, O, num_batches, seq_len, scale, true,
                                          static_cast<hipStream_t>(stream));
 }
 
-const char* fa_mi355_version(void) { return "fa_mi355 0.1.0 gfx950"; }
+FA_EXPORT const char* fa_mi355_version(void) { return "fa_mi355 0.1.0 gfx950"; }
 
 }  // extern "C"

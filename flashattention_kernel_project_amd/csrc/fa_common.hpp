@@ -158,4 +158,18 @@ static inline hipError_t ensure_dyn_lds(const void* kernel, int bytes) {
     return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// CU count of the CURRENT device, read per call (a one-process multi-GPU host drives several devices).
+static inline int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+// Launch bracket: drop whatever error an unrelated earlier call left on this thread, launch, then report
+// only this launch's own status.
+#define FA_LAUNCH(...)                         \
+    do {                                       \
+        (void)hipGetLastError();               \
+        hipLaunchKernelGGL(__VA_ARGS__);       \
+    } while (0)
+
 }  // namespace fa

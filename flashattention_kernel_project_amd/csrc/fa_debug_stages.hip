@@ -183,14 +183,14 @@ static hipError_t debug_stage_t(int stage, const void* A, const void* B, void* O
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(B);
     if (stage == 1) {
-        if (D == 64) hipLaunchKernelGGL((fa_debug_qk_kernel<T, 64>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb, scale);
-        else         hipLaunchKernelGGL((fa_debug_qk_kernel<T, 128>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb, scale);
+        if (D == 64) FA_LAUNCH((fa_debug_qk_kernel<T, 64>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb, scale);
+        else         FA_LAUNCH((fa_debug_qk_kernel<T, 128>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb, scale);
     } else if (stage == 2) {
-        hipLaunchKernelGGL((fa_debug_softmax_kernel<T>), dim3((unsigned)((long long)BH * N)), dim3(64), 0, stream,
+        FA_LAUNCH((fa_debug_softmax_kernel<T>), dim3((unsigned)((long long)BH * N)), dim3(64), 0, stream,
                            static_cast<const float*>(A), static_cast<uint16_t*>(Out), N);
     } else {
-        if (D == 64) hipLaunchKernelGGL((fa_debug_pv_kernel<T, 64>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb);
-        else         hipLaunchKernelGGL((fa_debug_pv_kernel<T, 128>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb);
+        if (D == 64) FA_LAUNCH((fa_debug_pv_kernel<T, 64>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb);
+        else         FA_LAUNCH((fa_debug_pv_kernel<T, 128>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb);
     }
     return hipGetLastError();
 }

@@ -588,9 +588,7 @@ static hipError_t launch_il(const void* Q, const void* K, const void* V, void* O
 {
     using G = TileGeom<D>;
     auto kern = fa_fwd_il_kernel<T, D, kOutF32, W>;
-    // FA_IL_LDS_BYTES (experiments only): request more LDS than needed to lower the occupancy
-    static const int lds_req = [] { const char* v = getenv("FA_IL_LDS_BYTES"); return v ? atoi(v) : 0; }();
-    const int lds_bytes = lds_req > G::kLdsBytes ? lds_req : G::kLdsBytes;
+    const int lds_bytes = G::kLdsBytes;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
@@ -598,21 +596,16 @@ static hipError_t launch_il(const void* Q, const void* K, const void* V, void* O
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     // persistent grid: one resident generation of workgroups (8 waves per CU at <= 256 VGPRs)
-    static const int grid_cap = [] {
-        const char* v = getenv("FA_IL_GRID");   // experiments: 0 = one workgroup per item
-        if (v) return atoi(v);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus * (8 / W);
-    }();
+    const int grid_cap = device_cus() * (8 / W);
     const unsigned grid = (grid_cap > 0 && nwg > grid_cap) ? (unsigned)grid_cap : (unsigned)nwg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds_bytes, stream,
+    FA_LAUNCH(kern, dim3(grid), dim3(64 * W), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e,
                        static_cast<unsigned long long*>(nullptr), (unsigned)nwg);
     return hipGetLastError();
 }
 
+#ifdef FA_EXPERIMENTS
 // Diagnostic launch (fp16, d=64, fp32 out): diag[nwg][W][4].
 hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream)
@@ -623,7 +616,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
         const int lds = 96 * 1024;   // more than half of the CU's LDS: occupancy 1
         auto go = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(256), lds, stream,
+            FA_LAUNCH(kern, dim3((unsigned)(BH * nqb)), dim3(256), lds, stream,
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                                static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
         };
@@ -647,7 +640,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
     if (waves >= 100) {   // the same ablations WITHOUT the in-kernel stamps (time them with events)
         const int nqb = (N + 255) / 256;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
+            FA_LAUNCH(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                                static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
         };
@@ -676,7 +669,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
     if (waves >= 10) {   // 8-wave workgroups with one piece of the iteration removed (timing only, wrong results)
         const int nqb = (N + 255) / 256;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
+            FA_LAUNCH(kern, dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
                                static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                                static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
         };
@@ -697,17 +690,18 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
     }
     if (waves == 8) {
         const int nqb = (N + 255) / 256;
-        hipLaunchKernelGGL((fa_fwd_il_kernel<F16, 64, true, 8, true>), dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
+        FA_LAUNCH((fa_fwd_il_kernel<F16, 64, true, 8, true>), dim3((unsigned)(BH * nqb)), dim3(512), G::kLdsBytes, stream,
                            static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                            static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
     } else {
         const int nqb = (N + 127) / 128;
-        hipLaunchKernelGGL((fa_fwd_il_kernel<F16, 64, true, 4, true>), dim3((unsigned)(BH * nqb)), dim3(256), G::kLdsBytes, stream,
+        FA_LAUNCH((fa_fwd_il_kernel<F16, 64, true, 4, true>), dim3((unsigned)(BH * nqb)), dim3(256), G::kLdsBytes, stream,
                            static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                            static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
     }
     return hipGetLastError();
 }
+#endif  // FA_EXPERIMENTS
 
 // waves: 8 = one 256-row workgroup per CU, 4 = two 128-row workgroups per CU
 hipError_t il_dispatch(const void* Q, const void* K, const void* V, void* O,

@@ -404,7 +404,7 @@ static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void
     const int nqb = (N + 32 * W - 1) / (32 * W);
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * W), G::kLdsBytes, stream,
+    FA_LAUNCH(kern, dim3((unsigned)nwg), dim3(64 * W), G::kLdsBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e);
     return hipGetLastError();
@@ -417,7 +417,7 @@ static hipError_t launch_generic(const void* Q, const void* K, const void* V, vo
     const int nqb = (N + 15) / 16;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((fa_fwd_generic_kernel<T, kOutF32, kCausal>), dim3((unsigned)nwg), dim3(64), 0, stream,
+    FA_LAUNCH((fa_fwd_generic_kernel<T, kOutF32, kCausal>), dim3((unsigned)nwg), dim3(64), 0, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, D, nqb, scale * kLog2e);
     return hipGetLastError();
@@ -483,6 +483,12 @@ hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
 hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream);
+hipError_t rp_dispatch(const void* Q, const void* K, const void* V, void* O,
+                       int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
+                       hipStream_t stream);
+hipError_t sk_dispatch(const void* Q, const void* K, const void* V, void* O,
+                       int BH, int N, int D, float scale, int in_dtype, int out_dtype, int variant,
+                       hipStream_t stream);
 hipError_t w64m_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream);
@@ -521,21 +527,30 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     }
     // d = 128: the same stream with two 16-row blocks per wave (fa_fwd_w64x.hip; 256-row workgroups)
     if (algo == 0 && D == 128) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 21) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
+    if (algo == 22) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
+    if (algo == 17) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
+    if (algo == 18) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);   // exact pass only
+#ifdef FA_EXPERIMENTS
+    if (algo == 19 || algo == 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 7 || algo == 8) {   // experimental occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out
+    if (algo == 7 || algo == 8) {   // occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out
         if (D != 64 || in_dtype != 0 || out_dtype != 0) return hipErrorInvalidValue;
         return algo == 7 ? launch_tiled<F16, 64, true, 4, 3>(Q, K, V, O, BH, N, scale, stream)
                          : launch_tiled<F16, 64, true, 4, 2>(Q, K, V, O, BH, N, scale, stream);
     }
     if (algo == 12) return il2x16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 14) return w64p_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 15) return w64m_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 11) return il16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
+#else
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 12) || algo == 14 || algo == 15 || algo == 19 || algo == 20 || algo > 22) return hipErrorInvalidValue;
+#endif
     if (algo == 5) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 8, stream);
     if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (in_dtype == 0)

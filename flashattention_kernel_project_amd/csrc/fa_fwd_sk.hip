@@ -1,0 +1,500 @@
+// fa_fwd_sk.hip -- attention forward, d = 64: 64 query rows per wave on v_mfma_f32_32x32x16, two wave groups
+// running half a tile apart ("skewed halves"), single-instruction fp32 vector work.
+//
+// What decides this kernel (tools/microbench/slot_model.hip, profiles/r02_slot_model.txt; cycles per 32x32x16
+// MFMA slot = the matrix work that stands for two scores per lane at d = 64, two waves per SIMD):
+//     vector work of a slot                                       alone    beside its MFMA
+//     1 v_pk_fma_f32 + 2 v_exp + 1 v_pk_add_f32 + 1 v_cvt_pk      29.7        81.2   <- the round-1 kernels
+//     2 v_fma_f32 + 2 v_exp + 2 v_add_f32 + 1 v_cvt_pk            35.6        45.5
+//     2 v_exp + 2 v_add_f32 + 1 v_cvt_pk  (scale folded into Q)   28.7        37.1
+//     the same three on two v_mfma_f32_16x16x32                            72.4 / 55.7 / 47.1
+// Packed fp32 instructions are the cheapest form in a vector-only phase and by far the dearest beside matrix
+// instructions (they stall behind the matrix pipe), which is why every schedule of round 1 that tried to overlap
+// the two pipes measured the same as the ones that did not.  Hence here:
+//   * no packed fp32 arithmetic anywhere in the loop (the build uses -fno-slp-vectorize, the source is scalar);
+//   * 32x32x16: an MFMA holds the SIMD's issue port for 8 of its 32 cycles (8 of 16 for 16x16x32);
+//   * fast pass: Q is multiplied by scale*log2(e) once and rounded to fp16, the accumulator chain of S^T = K.Q'^T
+//     starts at -m_ref (tile 0: at 0, and m_ref = its row max + 4), so p = 2^s' needs no arithmetic at all --
+//     exact pass (fallback, and always for bf16): p = 2^(c*s - m) with one v_fma_f32 per score and the lazy
+//     running max.  The fast pass is accepted only if no row sum reached the fp16 range, the rounded Q' stayed in
+//     fp16's normal range and the reference maximum is below kFoldMax (the rounding of Q' moves a logit by at most
+//     |logit| * 2^-11; at kFoldMax = 24 that is 1.2e-2 in the exponent, 0.8 % on a weight, and N(0,1) inputs sit at
+//     |logit| < 8); otherwise the workgroup re-runs the exact pass.  tests: test_forced_rescale_branch,
+//     test_optimistic_pass_overflow_fallback, test_large_logits, test_fold_gate_*.
+//   * waves 4-7 run half an iteration behind waves 0-3: an iteration is H1 = {K(t+1) -> LDS; S^T = K.Q^T; softmax of
+//     the first half of the scores} | barrier | H2 = {V(t+1) -> LDS; softmax of the second half; O^T += V^T.P^T} |
+//     barrier, so on every SIMD a wave that issues matrix instructions sits beside one that issues vector
+//     instructions (the SIMD arbitrates its two waves by age; in lock-step the older wave runs unimpeded and then
+//     waits 1 500 cycles per tile at the barrier: profiles/r02_ablation_w64x.txt).  This is the loader/compute
+//     hand-off of the reference's warp-specialised kernels (flashattn_warp_spc/..._v10.cu:188-269, one barrier per
+//     phase, MMA beside load; _v11.cu:189-258, fixed roles) turned into roles that alternate in time: with 64-lane
+//     waves and one matrix pipe per SIMD a dedicated loader wave would idle a quarter of the register file.
+//
+// Lane roles, LDS images, staging and the XCD-aware persistent grid are those of fa_fwd_w64.hip (K row-major,
+// 16-B chunks XOR-swizzled; V in [key/4][d/32] blocks for ds_read_b64_tr_b16).
+#include "fa_tile.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace fa {
+
+namespace sk {
+template <int... I, typename F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+#ifndef FA_SK_AHEAD
+#define FA_SK_AHEAD 2
+#endif
+#ifndef FA_SK_SKEW
+#define FA_SK_SKEW 1
+#endif
+#ifndef FA_SK_PRIO
+#define FA_SK_PRIO 0   // 1: s_setprio 1 around the matrix parts (QK^T, PV), 0 elsewhere
+#endif
+constexpr int kW = 8;
+constexpr int kAhead = FA_SK_AHEAD, kRing = kAhead + 1;
+constexpr float kHeadroom = 4.0f;
+constexpr float kFoldMax = 24.0f;   // fast pass only while the reference maximum (log2 units) stays below this
+}  // namespace sk
+
+// X = 32-row query blocks per wave (2 at D = 64).  kFold: fast pass with the scale folded into Q (fp16 only).
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kSkew, bool kDiag = false>
+__global__ __launch_bounds__(64 * sk::kW, 2)
+void fa_fwd_sk_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                      const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                      int N, int nqb, float scale_log2e, unsigned total_wg, unsigned long long* __restrict__ diag = nullptr)
+{
+    // kDiag (measurement build only, tools/lab_sk.py): s_memtime per phase, summed per wave into diag[wg][wave][8]
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+#define SK_STAMP(slot)                                                                   \
+    if constexpr (kDiag) {                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long now_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");     \
+        acc[slot] += now_ - last;                                                        \
+        last = now_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    }
+    using namespace sk;
+    using G = TileGeom<D>;
+    static_assert(!kFold || T::id == 0, "the folded pass rounds Q*scale to fp16");
+    constexpr int kRows = 32 * X * kW;
+    constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);
+    static_assert(kLoads == 1, "one 16-B chunk of K and of V per thread and tile");
+    constexpr int kUnits = 4 * X;   // softmax units of 8 scores per lane: (block x, quarter q4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][K tile][V tile]
+
+    const unsigned tid  = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane = tid & 63u;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const float c = fabsf(scale_log2e);
+    const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
+    const int ntiles = (N + kBlockN - 1) / kBlockN;
+    const bool partial = (N % kBlockN) != 0;
+    const bool late = kSkew && wave >= kW / 2;
+
+    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
+    const unsigned st_goff = srow * G::kRowBytes + sch * 16u;
+    const unsigned k_lds = G::k_off(srow, sch);
+    const unsigned v_lds = G::kTileBytes + G::v_off(srow, sch);
+
+    const unsigned k_rd_row = r * G::kRowBytes;
+    const unsigned k_rd_swz = G::k_swz(r);
+    const unsigned i16 = lane & 15u, vq = i16 >> 2, vp = i16 & 3u, vg = (lane >> 4) & 1u;
+    unsigned v_rd[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        v_rd[par] = G::kTileBytes + h * G::kDBlocks * 256u + ((vq ^ par) << 6) + vg * 32u + vp * 8u;
+
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
+    const std::true_type yes{};
+    const std::false_type no{};
+
+    const unsigned nwg = total_wg;
+    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    if (bid != blockIdx.x) __syncthreads();
+    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const unsigned bh = wgid / (unsigned)nqb;
+    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+    const unsigned q_row0 = qb * kRows + wave * (32u * X) + r;   // row of query block 0; block x is 32x rows further
+
+    u32x4 qf[X][G::kKSteps];   // B operand of QK^T
+    f32x16 o[X][G::kDBlocks];
+    float m_ref[X] = {}, l_part[X] = {};
+    u32x4 kst, vst;
+    int q_bad = 0;             // folded Q left fp16's normal range
+
+    // exact: Q as stored (sign of the scale folded in); folded: fp16(Q * scale * log2 e)
+    auto load_q = [&](auto fold_c) __attribute__((always_inline)) {
+        constexpr bool fold = decltype(fold_c)::value;
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            float amax = 0.0f;   // largest |Q'| among this lane's elements of the row
+#pragma unroll
+            for (int s = 0; s < G::kKSteps; ++s) {
+                u32x4 raw = buf_load16(rq, (q_row0 + 32u * x) * G::kRowBytes + (16u * s + 8u * h) * 2u);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if constexpr (fold) {
+                        const float lo = T::lo(raw[w]) * scale_log2e, hi = T::hi(raw[w]) * scale_log2e;
+                        amax = max3(amax, fabsf(lo), fabsf(hi));
+                        raw[w] = T::pack2(lo, hi);
+                    } else {
+                        raw[w] ^= q_flip;
+                    }
+                }
+                qf[x][s] = raw;
+            }
+            // the rounding to fp16 keeps 11 bits only inside the normal range: reject an overflow (or NaN) and a row
+            // whose elements ALL fell below it (branch-free; the flag is per lane, joined over the workgroup later)
+            if constexpr (fold) q_bad |= (int)!(amax <= 65504.0f) | ((int)(amax != 0.0f) & (int)(amax < 6.2e-5f));
+        }
+    };
+
+    // mode: 0 fast (folded, reference max fixed after tile 0), 1 exact with the reference max fixed after tile 0,
+    //       2 exact with the lazy running max
+    auto run = [&](auto mode_c) __attribute__((always_inline)) {
+        constexpr int kMode = decltype(mode_c)::value;
+        constexpr bool kFast = kMode == 0, kTrack = kMode == 2;
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+#pragma unroll
+            for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
+            l_part[x] = 0.0f;
+        }
+        // tile 0 -> buffer 0, tile 1 on its way
+        kst = buf_load16(rk, st_goff);
+        vst = buf_load16(rv, st_goff);
+        lds_write16(smem, k_lds, kst);
+        lds_write16(smem, v_lds, vst);
+        kst = buf_load16(rk, G::kTileBytes + st_goff);
+        vst = buf_load16(rv, G::kTileBytes + st_goff);
+        __syncthreads();
+        if (late) __syncthreads();   // waves 4-7 sit out the first half-iteration
+        if constexpr (kDiag) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last)::"memory");
+
+        f32x16 s[X][2];
+        f32x16 minit[X];             // fast pass: the accumulator chains of tiles >= 1 start at -m_ref
+        u32x4 pk[X][4];
+        u32x4 frag[kRing];
+
+        auto qk = [&](unsigned cur, auto first_c) __attribute__((always_inline)) {
+            constexpr bool first = decltype(first_c)::value;
+            auto read_k = [&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr (f < 2 * G::kKSteps) {
+                    constexpr int kb = f % 2, ks = f / 2;
+                    frag[f % kRing] = lds_read16(smem, cur * G::kBufBytes + kb * 32u * G::kRowBytes + k_rd_row +
+                                                           (((2u * ks + h) ^ k_rd_swz) << 4));
+                }
+            };
+            sfor<kAhead>([&](auto fc) { read_k(fc); });
+            sfor<2 * G::kKSteps>([&](auto fc) {
+                constexpr int f = decltype(fc)::value, kb = f % 2, ks = f / 2;
+#pragma unroll
+                for (int x = 0; x < X; ++x)
+                    s[x][kb] = T::mfma32(frag[f % kRing], qf[x][ks], ks == 0 ? ((kFast && !first) ? minit[x] : zero16) : s[x][kb]);
+                read_k(std::integral_constant<int, f + kAhead>{});
+            });
+        };
+        auto mask_tail = [&](int t) __attribute__((always_inline)) {   // keys >= N -> -inf (p = 0)
+#pragma unroll
+            for (int x = 0; x < X; ++x)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = t * kBlockN + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                        if (key >= N) s[x][kb][i] = -INFINITY;
+                    }
+        };
+        auto row_max = [&](int x) __attribute__((always_inline)) -> float {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 32; e += 2) tmax = max3(tmax, s[x][e >> 4][e & 15], s[x][(e + 1) >> 4][(e + 1) & 15]);
+            return tmax;
+        };
+        // softmax of units [u0, u1): unit u = (block u / 4, quarter u % 4) = 8 scores per lane -> one B fragment of PV
+        auto softmax = [&](auto u0c, auto u1c, auto first_c) __attribute__((always_inline)) {
+            constexpr int u0 = decltype(u0c)::value, u1 = decltype(u1c)::value;
+            constexpr bool first = decltype(first_c)::value;
+            sfor<u1 - u0>([&](auto ic) {
+                constexpr int u = u0 + decltype(ic)::value, x = u / 4, q4 = u % 4, kb = q4 >> 1, b8 = (q4 & 1) * 8;
+                float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    float v0 = s[x][kb][b8 + 2 * w], v1 = s[x][kb][b8 + 2 * w + 1];
+                    if constexpr (!kFast) {
+                        v0 = __builtin_fmaf(v0, c, -m_ref[x]);
+                        v1 = __builtin_fmaf(v1, c, -m_ref[x]);
+                    } else if constexpr (first) {
+                        v0 -= m_ref[x];
+                        v1 -= m_ref[x];
+                    }
+                    const float p0 = fast_exp2(v0), p1 = fast_exp2(v1);
+                    pk[x][q4][w] = T::pack2(p0, p1);
+                    if constexpr (T::kSumRounded) {
+                        if (w & 1) ls1 = T::sum2(pk[x][q4][w], ls1);
+                        else ls0 = T::sum2(pk[x][q4][w], ls0);
+                    } else {
+                        ls0 += p0;
+                        ls1 += p1;
+                    }
+                }
+                l_part[x] += ls0 + ls1;
+            });
+        };
+        auto pv = [&](unsigned cur) __attribute__((always_inline)) {
+            auto read_v = [&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                if constexpr (f < 4 * G::kDBlocks) {
+                    constexpr int db = f % G::kDBlocks, ks = f / G::kDBlocks;
+                    u32x4 vf;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const u32x2 half = lds_read_tr8(
+                            smem, cur * G::kBufBytes + v_rd[db & 1] + ((4u * ks + 2u * jj) * G::kDBlocks + db) * 256u);
+                        vf[2 * jj] = half[0];
+                        vf[2 * jj + 1] = half[1];
+                    }
+                    frag[f % kRing] = vf;
+                }
+            };
+            sfor<kAhead>([&](auto fc) { read_v(fc); });
+            sfor<4 * G::kDBlocks>([&](auto fc) {
+                constexpr int f = decltype(fc)::value, db = f % G::kDBlocks, ks = f / G::kDBlocks;
+#pragma unroll
+                for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(frag[f % kRing], pk[x][ks], o[x][db]);
+                read_v(std::integral_constant<int, f + kAhead>{});
+            });
+        };
+        const std::integral_constant<int, 0> u_lo{};
+        const std::integral_constant<int, kUnits / 2> u_mid{};
+        const std::integral_constant<int, kUnits> u_hi{};
+
+        auto tile = [&](int t, auto first_c) __attribute__((always_inline)) {
+            constexpr bool first = decltype(first_c)::value;
+            const unsigned cur = (unsigned)t & 1u, nxt = cur ^ 1u;
+            // ---- H1: K(t+1) -> LDS, K(t+2) on its way; S^T = K.Q^T; first half of the softmax ----
+            lds_write16(smem, nxt * G::kBufBytes + k_lds, kst);
+            kst = buf_load16(rk, (unsigned)(t + 2) * G::kTileBytes + st_goff);
+            SK_STAMP(0)
+            if constexpr (FA_SK_PRIO) __builtin_amdgcn_s_setprio(1);
+            qk(cur, first_c);
+            if constexpr (FA_SK_PRIO) __builtin_amdgcn_s_setprio(0);
+            SK_STAMP(1)
+            if (partial && t + 1 == ntiles) mask_tail(t);
+            if constexpr (first) {
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    const float tmax = row_max(x) * (kFast ? 1.0f : c);
+                    m_ref[x] = fmaxf(tmax, swap_halves(tmax)) + (kTrack ? 0.0f : kHeadroom);
+                    if constexpr (kFast) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) minit[x][i] = -m_ref[x];
+                    }
+                }
+            } else if constexpr (kTrack) {
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    const float tmax = row_max(x) * c;
+                    if (__any(tmax - m_ref[x] > kThr)) {
+                        const float m_new = fmaxf(fmaxf(tmax, swap_halves(tmax)), m_ref[x]);
+                        const float alpha = fast_exp2(m_ref[x] - m_new);
+                        m_ref[x] = m_new;
+#pragma unroll
+                        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) o[x][db][i] *= alpha;
+                        l_part[x] *= alpha;
+                    }
+                }
+            }
+            softmax(u_lo, u_mid, first_c);
+            SK_STAMP(2)
+            __syncthreads();
+            SK_STAMP(3)
+            // ---- H2: V(t+1) -> LDS, V(t+2) on its way; second half of the softmax; O^T += V^T.P^T ----
+            lds_write16(smem, nxt * G::kBufBytes + v_lds, vst);
+            vst = buf_load16(rv, (unsigned)(t + 2) * G::kTileBytes + st_goff);
+            SK_STAMP(4)
+            softmax(u_mid, u_hi, first_c);
+            SK_STAMP(5)
+            if constexpr (FA_SK_PRIO) __builtin_amdgcn_s_setprio(1);
+            pv(cur);
+            if constexpr (FA_SK_PRIO) __builtin_amdgcn_s_setprio(0);
+            SK_STAMP(6)
+            __syncthreads();
+            SK_STAMP(7)
+        };
+        tile(0, yes);
+        for (int t = 1; t < ntiles; ++t) tile(t, no);
+        if (kSkew && !late) __syncthreads();   // waves 0-3 sit out the last half-iteration
+    };
+
+    float l_row[X];
+    auto finish = [&](float lim) __attribute__((always_inline)) -> bool {
+        bool bad = false;
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            l_row[x] = l_part[x] + swap_halves(l_part[x]);
+            bad = bad || !(l_row[x] < lim);
+        }
+        return bad;
+    };
+    // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range; bf16 keeps a finite
+    // bound with room for sum(p*v) in fp32 (2^96 * |V| * N stays finite)
+    const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
+    bool redo;
+    if constexpr (kFold) {
+        load_q(yes);
+        run(std::integral_constant<int, 0>{});
+        bool bad = finish(lim) || q_bad != 0;
+#pragma unroll
+        for (int x = 0; x < X; ++x) bad = bad || !(fabsf(m_ref[x]) <= kFoldMax);
+        redo = __syncthreads_or(bad ? 1 : 0) != 0;
+        if (redo) load_q(no);
+    } else {
+        load_q(no);
+        run(std::integral_constant<int, 1>{});
+        redo = __syncthreads_or(finish(lim) ? 1 : 0) != 0;
+    }
+    if (redo) {
+        run(std::integral_constant<int, 2>{});
+        (void)finish(lim);
+    }
+
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+#pragma unroll
+    for (int x = 0; x < X; ++x) {
+        const float inv = 1.0f / l_row[x];
+        const unsigned row = q_row0 + 32u * x;
+#pragma unroll
+        for (int db = 0; db < G::kDBlocks; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned col = db * 32u + 8u * g + 4u * h;
+                const float a = o[x][db][4 * g] * inv, b = o[x][db][4 * g + 1] * inv;
+                const float cc = o[x][db][4 * g + 2] * inv, d = o[x][db][4 * g + 3] * inv;
+                if constexpr (kOutF32) {
+                    const f32x4 v = {a, b, cc, d};
+                    buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+                } else {
+                    buf_store8(ro, (row * D + col) * 2u, u32x2{T::pack2(a, b), T::pack2(cc, d)});
+                }
+            }
+    }
+    }   // persistent loop over work items
+    if constexpr (kDiag) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) diag[((size_t)blockIdx.x * kW + wave) * 8 + i] = acc[i];
+        }
+    }
+#undef SK_STAMP
+}
+
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kSkew>
+static hipError_t launch_sk(const void* Q, const void* K, const void* V, void* O,
+                            int BH, int N, float scale, hipStream_t stream)
+{
+    using G = TileGeom<D>;
+    constexpr int kRows = 32 * X * sk::kW;
+    const int nqb = (N + kRows - 1) / kRows;
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const long long cap = device_cus();
+    const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
+    auto kern = fa_fwd_sk_kernel<T, D, X, kOutF32, kFold, kSkew>;
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 2 * G::kBufBytes);
+    if (attr != hipSuccess) return attr;
+    FA_LAUNCH(kern, dim3(grid), dim3(64 * sk::kW), 2 * G::kBufBytes, stream,
+              static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
+              static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg,
+              static_cast<unsigned long long*>(nullptr));
+    return hipGetLastError();
+}
+
+#ifdef FA_EXPERIMENTS
+// measurement build: fp16 -> fp32 with per-phase stamps (variant as below)
+hipError_t sk_diag_dispatch(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale, int variant,
+                            unsigned long long* diag, hipStream_t stream)
+{
+    using G = TileGeom<64>;
+    const int nqb = (N + 511) / 512;
+    const long long nwg = (long long)BH * nqb;
+    const long long cap = device_cus();
+    const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
+    auto go = [&](auto kern) {
+        FA_LAUNCH(kern, dim3(grid), dim3(64 * sk::kW), 2 * G::kBufBytes, stream,
+                  static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb,
+                  scale * kLog2e, (unsigned)nwg, diag);
+        return hipGetLastError();
+    };
+    switch (variant) {
+        case 0: return go(fa_fwd_sk_kernel<F16, 64, 2, true, true, true, true>);
+        case 1: return go(fa_fwd_sk_kernel<F16, 64, 2, true, false, true, true>);
+        case 2: return go(fa_fwd_sk_kernel<F16, 64, 2, true, true, false, true>);
+        case 3: return go(fa_fwd_sk_kernel<F16, 64, 2, true, false, false, true>);
+        default: return hipErrorInvalidValue;
+    }
+}
+#endif
+
+// variant (experiments): 0 = shipped (fold for fp16, skew), 1 = no fold, 2 = no skew, 3 = neither
+hipError_t sk_dispatch(const void* Q, const void* K, const void* V, void* O,
+                       int BH, int N, int D, float scale, int in_dtype, int out_dtype, int variant,
+                       hipStream_t stream)
+{
+    if (D != 64) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * sk::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (!(scale == scale) || scale * kLog2e == 0.0f) variant |= 1;   // NaN / zero scale: the exact pass defines the result
+#ifdef FA_EXPERIMENTS
+#define SK_GO(T, OUT, FOLD, SKEW) return launch_sk<T, 64, 2, OUT, FOLD, SKEW>(Q, K, V, O, BH, N, scale, stream)
+    if (in_dtype == 0) {
+        if (out_dtype == 0) {
+            if (variant == 0) SK_GO(F16, true, true, true);
+            if (variant == 1) SK_GO(F16, true, false, true);
+            if (variant == 2) SK_GO(F16, true, true, false);
+            SK_GO(F16, true, false, false);
+        }
+        if (variant & 1) SK_GO(F16, false, false, true);
+        SK_GO(F16, false, true, true);
+    }
+    if (out_dtype == 0) {
+        if (variant & 2) SK_GO(BF16, true, false, false);
+        SK_GO(BF16, true, false, true);
+    }
+    SK_GO(BF16, false, false, true);
+#undef SK_GO
+#else
+    if (in_dtype == 0) {
+        if (variant & 1)
+            return out_dtype == 0 ? launch_sk<F16, 64, 2, true, false, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_sk<F16, 64, 2, false, false, true>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_sk<F16, 64, 2, true, true, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_sk<F16, 64, 2, false, true, true>(Q, K, V, O, BH, N, scale, stream);
+    }
+    return out_dtype == 0 ? launch_sk<BF16, 64, 2, true, false, true>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_sk<BF16, 64, 2, false, false, true>(Q, K, V, O, BH, N, scale, stream);
+#endif
+}
+
+}  // namespace fa

@@ -314,9 +314,7 @@ int split_count(int BH, int Nq, int Nk)
 {
     const long long base = (long long)BH * ((Nq + split::kRows - 1) / split::kRows);
     const int tiles = (Nk + kBlockN - 1) / kBlockN;
-    // experiments: FA_SPLIT_TARGET workgroups in total, at least FA_SPLIT_MIN_TILES tiles per split
-    static const int target = [] { const char* v = getenv("FA_SPLIT_TARGET"); return v ? atoi(v) : 1024; }();
-    static const int min_tiles = [] { const char* v = getenv("FA_SPLIT_MIN_TILES"); return v ? atoi(v) : 4; }();
+    constexpr int target = 1024, min_tiles = 4;   // workgroups in total, fewest tiles per split
     long long s = (target + base - 1) / base;   // about four workgroups per CU
     if (s > tiles / min_tiles) s = tiles / min_tiles;
     if (s < 1) s = 1;
@@ -348,17 +346,17 @@ static hipError_t launch_split(const void* Q, const void* K, const void* V, void
     if (attr == hipSuccess) attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_split_kernel<T, D, kOutF32, true>), G::kLdsBytes);
     if (attr != hipSuccess) return attr;
     if (S == 1) {
-        hipLaunchKernelGGL((fa_fwd_split_kernel<T, D, kOutF32, false>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,
+        FA_LAUNCH((fa_fwd_split_kernel<T, D, kOutF32, false>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,
                            stream, q, k, v, O, static_cast<float*>(nullptr), Nq, Nk, nqb, S, chunk, scale * kLog2e);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((fa_fwd_split_kernel<T, D, kOutF32, true>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,
+    FA_LAUNCH((fa_fwd_split_kernel<T, D, kOutF32, true>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,
                        stream, q, k, v, O, static_cast<float*>(ws), Nq, Nk, nqb, S, chunk, scale * kLog2e);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long long rows = (long long)BH * Nq;   // one wave per output row
     if (rows > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((fa_split_combine_kernel<T, kOutF32>), dim3((unsigned)rows), dim3(64), 0, stream,
+    FA_LAUNCH((fa_split_combine_kernel<T, kOutF32>), dim3((unsigned)rows), dim3(64), 0, stream,
                        static_cast<const float*>(ws), O, BH, Nq, D, S);
     return hipGetLastError();
 }

@@ -393,17 +393,13 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    static const int grid_cap = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus;
-    }();
+    const int grid_cap = device_cus();
     const long long cap = (long long)grid_cap * (8 / kW);
     const unsigned grid = (nwg > cap && !kCausal) ? (unsigned)cap : (unsigned)nwg;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal, kW>),
                                            2 * FA_W64_BARRIER_EVERY * G::kBufBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal, kW>), dim3(grid), dim3(64 * kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
+    FA_LAUNCH((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal, kW>), dim3(grid), dim3(64 * kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();

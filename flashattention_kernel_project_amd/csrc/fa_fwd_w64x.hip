@@ -360,16 +360,12 @@ static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void*
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    static const int grid_cap = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus;
-    }();
+    const int grid_cap = device_cus();
     const long long cap = (long long)grid_cap * (8 / w64x::kW);
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(&fa_fwd_w64x_kernel<T, D, X, kOutF32>), lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fa_fwd_w64x_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64x::kW), lds_bytes, stream,
+    FA_LAUNCH((fa_fwd_w64x_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64x::kW), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
     return hipGetLastError();

@@ -101,10 +101,10 @@ hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, flo
     const unsigned grid = (unsigned)((num_batches + kS16WavesPerBlock - 1) / kS16WavesPerBlock);
     const float c = scale * kLog2e;
     if (k_transposed)
-        hipLaunchKernelGGL(fa_streaming16_kernel<true>, dim3(grid), dim3(64 * kS16WavesPerBlock), 0, stream,
+        FA_LAUNCH(fa_streaming16_kernel<true>, dim3(grid), dim3(64 * kS16WavesPerBlock), 0, stream,
                            (const uint16_t*)Q, (const uint16_t*)K, (const uint16_t*)V, O, num_batches, seq_len, c);
     else
-        hipLaunchKernelGGL(fa_streaming16_kernel<false>, dim3(grid), dim3(64 * kS16WavesPerBlock), 0, stream,
+        FA_LAUNCH(fa_streaming16_kernel<false>, dim3(grid), dim3(64 * kS16WavesPerBlock), 0, stream,
                            (const uint16_t*)Q, (const uint16_t*)K, (const uint16_t*)V, O, num_batches, seq_len, c);
     return hipGetLastError();
 }

@@ -122,6 +122,11 @@ int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, const void* 
 /* Library identification: "fa_mi355 <version> gfx950". */
 const char* fa_mi355_version(void);
 
+/* 1 when the library was built with the experimental A/B kernels (`make experimental`: explicit algo ids
+ * 3, 4, 7-12, 14, 15 and the measurement entry points), 0 for the product build, where those ids return
+ * hipErrorInvalidValue. */
+int fa_mi355_has_experiments(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Build a variant of the product library with extra -D flags into gpurun_variants/lib_<name>.so (A/B with tools/ab_libs.py).
+#   tools/build_variant.sh prio1 "-DFA_SK_PRIO=1"
+set -e
+name=$1; extra=$2
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/flashattention_kernel_project_amd/csrc
+out=$root/gpurun_variants; obj=$out/obj_$name
+mkdir -p "$obj"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -fvisibility=hidden -Wall -Wno-unused-function"
+SRCS="fa_fwd_kernels.hip fa_fwd_il.hip fa_fwd_w64.hip fa_fwd_w64x.hip fa_fwd_sk.hip fa_fwd_rp.hip fa_fwd_split.hip fa_debug_stages.hip fa_streaming16.hip fa_capi.hip"
+pids=()
+for s in $SRCS; do
+  # only fa_fwd_sk.hip and fa_capi.hip depend on the knobs in practice; the rest are reused from the product build
+  if [ "$s" = "fa_fwd_sk.hip" ] || [ "$s" = "fa_fwd_rp.hip" ] || [ ! -f "$src/${s%.hip}.o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS $extra -c "$src/$s" -o "$obj/${s%.hip}.o" &
+    pids+=($!)
+  else
+    cp "$src/${s%.hip}.o" "$obj/${s%.hip}.o"
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $obj/*.o -o "$out/lib_$name.so"
+echo "built $out/lib_$name.so"
