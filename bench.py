@@ -23,23 +23,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF)
+CONFIGS = {"cfg3": (4, 8, 1024, 64, "f16"), "cfg4": (8, 16, 4096, 64, "f16"), "cfg4bf16": (8, 16, 4096, 64, "bf16"),
+           "cfg5": (8, 16, 8192, 128, "f16")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults long enough for the clocks to settle: the first ~30 ms after idle run 5 % slower (50/10: 0.600 ms, 200/50: 0.569)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--H", type=int, default=16)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
     ap.add_argument("--out", choices=["f32", "same"], default="f32")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json shorthand: cfg3 (B4 H8 N1024 d64 fp16), cfg4 (B8 H16 N4096 d64 fp16, the metric config), "
+                         "cfg4bf16 (config 4 as written), cfg5 (one GPU's shard of B64 H16 N8192 d128 fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sustained", type=int, default=300,
+                    help="launches run AFTER the timed region and reported under `sustained` (the first ~30 ms after idle run "
+                         "slower while the clocks settle; never part of `value`); 0 disables")
     args = ap.parse_args()
+    if args.config:
+        args.B, args.H, args.N, args.d, args.dtype = CONFIGS[args.config]
 
     import torch
     import flashattention_kernel_project_amd as fa
@@ -68,6 +77,8 @@ def main():
     o = torch.empty(B, H, N, d, device=dev, dtype=odt)
     stream = torch.cuda.current_stream()
 
+    kernel_name = fa.lib().fa_selected_kernel(B, H, N, d, 0 if args.dtype == "f16" else 1, 0).decode()
+
     def step():
         fa.fa_forward(q, k, v, out=o, stream=stream)
 
@@ -91,13 +102,47 @@ def main():
     value = total_flops / wall / 1e12
     achieved = flops_per_gpu / (kern_ms * 1e-3) / 1e12
 
+    # after the timed region, outside `value`: the same launch back to back until the clocks have settled
+    sustained = None
+    if args.sustained > 0:
+        sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(args.sustained // 3):
+            step()
+        sv0.record(stream)
+        for _ in range(args.sustained):
+            step()
+        sv1.record(stream)
+        torch.cuda.synchronize()
+        s_ms = ranks.max_over_ranks(sv0.elapsed_time(sv1) / args.sustained, dev)
+        sustained = {"launches": args.sustained, "after_launches": args.warmup + args.steps + args.sustained // 3,
+                     "ms_per_step": round(s_ms, 5), "tflops_per_gpu": round(flops_per_gpu / (s_ms * 1e-3) / 1e12, 3),
+                     "frac": round(flops_per_gpu / (s_ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4)}
+    # N > 1: BASELINE config 5's per-GPU shard (B8 H16 N8192 d128) as an extra figure, a few launches
+    cfg5 = None
+    if world > 1 and (B, H, N, d) != (8, 16, 8192, 128):
+        q5, k5, v5 = (torch.randn(8, 16, 8192, 128, generator=g, device=dev, dtype=torch.float32).to(dt) for _ in range(3))
+        o5 = torch.empty(8, 16, 8192, 128, device=dev, dtype=odt)
+        for _ in range(3):
+            fa.fa_forward(q5, k5, v5, out=o5, stream=stream)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(10):
+            fa.fa_forward(q5, k5, v5, out=o5, stream=stream)
+        c1.record(stream)
+        torch.cuda.synchronize()
+        c_ms = ranks.max_over_ranks(c0.elapsed_time(c1) / 10, dev)
+        f5 = fa.attention_flops(128, 8192, 128)
+        cfg5 = {"workload": "B=8 H=16 N=8192 d=128 per GPU (config 5 shard)", "ms_per_step": round(c_ms, 4),
+                "tflops_per_gpu": round(f5 / (c_ms * 1e-3) / 1e12, 2), "tflops_all_gpus": round(world * f5 / (c_ms * 1e-3) / 1e12, 2)}
+        del q5, k5, v5, o5
+
     cpu = None
     if ranks.rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(q, k, v, o, N, d, args.cpu_seconds)
 
     if ranks.rank == 0:
         line = {
-            "metric": "attention-fwd TFLOP/s (and %MFMA-peak) at B8 H16 N4096 d64 fp16",
+            "metric": f"attention-fwd TFLOP/s (and %MFMA-peak) at B{B} H{H} N{N} d{d} {'fp16' if args.dtype == 'f16' else 'bf16'}",
             "value": round(value, 3),
             "unit": "TFLOP/s",
             "n_gpus": world,
@@ -116,13 +161,16 @@ def main():
             "pct_mfma_peak": round(100.0 * value / (PEAK_TFLOPS * world), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4),
-                         "traffic": measured_traffic(B, H, N, d, args.dtype, args.out),
-                         "kernel": "fa::fa_fwd_w64x_kernel" if d in (64, 128) else "fa::fa_fwd_generic_kernel", "avg_launch_ms": round(kern_ms, 5),
+                         "traffic": measured_traffic(B, H, N, d, args.dtype, args.out, kernel_name),
+                         "kernel": kernel_name, "avg_launch_ms": round(kern_ms, 5),
                          "algorithmic_bytes": fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2),
                          "hbm_GBps_algorithmic": round(fa.attention_min_bytes(B * H, N, d, 2, 4 if odt == torch.float32 else 2)
                                                        / (kern_ms * 1e-3) / 1e9, 1)},
             "cpu_baseline": cpu,
+            "sustained": sustained,
         }
+        if cfg5 is not None:
+            line["cfg5_per_gpu"] = cfg5
         print(json.dumps(line), flush=True)
     ranks.close()
 
@@ -172,7 +220,14 @@ def cpu_baseline(q, k, v, o_gpu, N, d, budget_s):
         got = o_gpu[0, 0, :rows].float().cpu().numpy()[None]
         what = f"{rows} query rows x {N} keys of head (b=0,h=0)"
     err = orc.max_abs(got, want)
+    # the same port on ONE thread (SURVEY 8(d) asks for both), on a row range sized for ~2 s
+    rows1 = max(8, min(N, int(2.0 * rate / max(threads, 1))))
+    t0 = time.perf_counter()
+    orc.forward(q0, k0, v0, accum=0, nthreads=1, row_range=(0, rows1))
+    dt1 = time.perf_counter() - t0
     return {"value": round(rows * flops_row / dt_ / 1e12, 6), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": round(rows1 * flops_row / dt1 / 1e12, 6), "unit": "TFLOP/s", "cores": 1,
+                              "sample": f"{rows1} query rows x {N} keys of head (b=0,h=0) in {dt1:.2f} s"},
             "sample": f"{what}, d={d}: {rows * flops_row / 1e9:.1f} GFLOP in {dt_:.2f} s on {threads} threads "
                       f"(oracle/attention_cpu.c, naive 3-loop fp32, OpenMP over rows)",
             "gpu_vs_cpu_max_abs_on_sample": float(err)}
@@ -183,16 +238,17 @@ def torch_stack(t, idx):
     return np.stack([t[b, h].float().cpu().numpy() for (b, h) in idx])
 
 
-def measured_traffic(B, H, N, d, dtype, out):
+def measured_traffic(B, H, N, d, dtype, out, kernel_name):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
     written by tools/collect_profiles.sh with the gfx950 FETCH_SIZE x2 correction), if they were
-    taken on this exact workload; else None."""
+    taken on this exact workload AND on the kernel this run dispatches; else None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         cfg = rec.get("config", {})
-        if (cfg.get("B"), cfg.get("H"), cfg.get("N"), cfg.get("d"), cfg.get("dtype"), cfg.get("out")) == (B, H, N, d, dtype, out):
+        same = (cfg.get("B"), cfg.get("H"), cfg.get("N"), cfg.get("d"), cfg.get("dtype"), cfg.get("out")) == (B, H, N, d, dtype, out)
+        if same and kernel_name and str(rec.get("kernel", "")).replace("void ", "").startswith(kernel_name):
             return rec.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass

@@ -13,6 +13,7 @@ F16, BF16 = 0, 1
 OUT_F32, OUT_SAME = 0, 1
 ALGO_AUTO, ALGO_GENERIC, ALGO_TILED, ALGO_PIPE, ALGO_PINGPONG, ALGO_INTERLEAVED, ALGO_INTERLEAVED_2WG = 0, 1, 2, 3, 4, 5, 6
 ALGO_TLP3, ALGO_IL16, ALGO_IL2X16, ALGO_W64, ALGO_W64P, ALGO_W64M, ALGO_W64X = 9, 11, 12, 13, 14, 15, 16
+ALGO_SK, ALGO_RP, ALGO_RP_FOLD = 17, 21, 22
 
 # every symbol include/fa_mi355.h declares
 SYMBOLS = (
@@ -27,6 +28,8 @@ SYMBOLS = (
     "flashattn_streaming_16x16_mw_kt",
     "fa_mi355_version",
     "fa_mi355_has_experiments",
+    "fa_selected_algo",
+    "fa_selected_kernel",
 )
 
 
@@ -84,10 +87,14 @@ def lib() -> C.CDLL:
         L.fa_debug_stage.argtypes = [i, vp, vp, vp, i, i, i, f, i, vp]
         L.flashattn_streaming_16x16_mw.argtypes = [vp, vp, vp, vp, i, i, f, vp]
         L.flashattn_streaming_16x16_mw_kt.argtypes = [vp, vp, vp, vp, i, i, f, vp]
-        for s in SYMBOLS[:-2]:
+        for s in SYMBOLS[:9]:
             getattr(L, s).restype = C.c_int
         L.fa_mi355_has_experiments.argtypes = []
         L.fa_mi355_has_experiments.restype = C.c_int
+        L.fa_selected_algo.argtypes = [i, i, i, i, i]
+        L.fa_selected_algo.restype = C.c_int
+        L.fa_selected_kernel.argtypes = [i, i, i, i, i, i]
+        L.fa_selected_kernel.restype = C.c_char_p
         L.fa_forward_splitkv_workspace_bytes.restype = C.c_size_t
         L.fa_mi355_version.argtypes = []
         L.fa_mi355_version.restype = C.c_char_p

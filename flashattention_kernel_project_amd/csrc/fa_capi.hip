@@ -17,6 +17,8 @@ hipError_t debug_stage_dispatch(int stage, const void* A, const void* B, void* O
 hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, float* O,
                                 int num_batches, int seq_len, float scale, bool k_transposed,
                                 hipStream_t stream);
+int auto_algo(int BH, int N, int D, int in_dtype);
+const char* algo_kernel_name(int algo, int D);
 #ifdef FA_EXPERIMENTS
 hipError_t pp_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, float scale, unsigned long long* diag, int mode, hipStream_t stream);
@@ -146,6 +148,18 @@ FA_EXPORT int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, co
                                          static_cast<hipStream_t>(stream));
 }
 
-FA_EXPORT const char* fa_mi355_version(void) { return "fa_mi355 0.1.0 gfx950"; }
+FA_EXPORT int fa_selected_algo(int B, int H, int N, int d, int in_dtype)
+{
+    if (B <= 0 || H <= 0 || N <= 0 || d <= 0 || (long long)B * H > 0x7FFFFFFFll) return -1;
+    return fa::auto_algo(B * H, N, d, in_dtype);
+}
+
+FA_EXPORT const char* fa_selected_kernel(int B, int H, int N, int d, int in_dtype, int algo)
+{
+    if (algo == FA_ALGO_AUTO) algo = fa_selected_algo(B, H, N, d, in_dtype);
+    return algo < 0 ? "" : fa::algo_kernel_name(algo, d);
+}
+
+FA_EXPORT const char* fa_mi355_version(void) { return "fa_mi355 0.2.0 gfx950"; }
 
 }  // extern "C"

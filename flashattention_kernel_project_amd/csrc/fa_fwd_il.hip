@@ -536,7 +536,7 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
     {
         // without the MFMA row sum: a packed p can only have overflowed if the fp32 row sum reached the format's range
         const float l_chk = FA_IL_MFMA_SUM ? o_l[0] : l_part + swap_halves(l_part);
-        const bool bad = !(__builtin_fabsf(l_chk) < (FA_IL_MFMA_SUM || T::id == 1 ? INFINITY : 60000.0f));
+        const bool bad = !(__builtin_fabsf(l_chk) < (FA_IL_MFMA_SUM || T::id == 1 ? 0x1p+96f : 60000.0f));
         if (__syncthreads_or(bad ? 1 : 0)) {
             __syncthreads();   // everybody is out of the first pass's LDS reads
             run(yes);

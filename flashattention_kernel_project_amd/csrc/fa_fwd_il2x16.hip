@@ -350,7 +350,7 @@ void fa_fwd_il2x16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __res
     float l_row[2] = {across_sum(l_part[0]), across_sum(l_part[1])};
     {
         // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
-        const float lim = T::id == 1 ? INFINITY : 60000.0f;
+        const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
         const bool bad = !(l_row[0] < lim) || !(l_row[1] < lim);
         if (__syncthreads_or(bad ? 1 : 0)) {
             __syncthreads();

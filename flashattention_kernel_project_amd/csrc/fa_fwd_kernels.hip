@@ -499,6 +499,41 @@ hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
                            int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                            hipStream_t stream);
 
+// AUTO: the explicit algo id a shape resolves to (one rule for the dispatcher and for fa_selected_kernel()).
+//   d = 64, N > 256 and at least one 512-row workgroup per CU: the rolling half-tile pipeline (fa_fwd_rp.hip), with the folded fast
+//     pass for fp16 (22) and the exact pass for bf16 (21) -- round 2, same device, sustained: fp16 0.542 vs 0.554 ms for
+//     fa_fwd_w64x, bf16 0.539 vs 0.547 for fa_fwd_w64;
+//   d = 64, smaller grids: the interleaved kernel with 256-row workgroups, or 128-row ones (two per CU);
+//   d = 128: fa_fwd_w64x for fp16 (3.86 vs 4.04 ms at N 8192), fa_fwd_w64 for bf16 (3.78 vs 3.92 ms);
+//   anything else: the generic single-fragment kernel.
+// The CU count is read from the current device per call.
+int auto_algo(int BH, int N, int D, int in_dtype)
+{
+    if (D == 64) {
+        const long long cus = device_cus();
+        const long long nwg512 = (long long)BH * ((N + 511) / 512);
+        if (N > 256 && nwg512 >= cus) return in_dtype == 0 ? 22 : 21;   // N <= 256 would leave half of every 512-row workgroup idle
+        const long long nwg256 = (long long)BH * ((N + 255) / 256);
+        return nwg256 >= 2 * cus ? 5 : 6;
+    }
+    if (D == 128) return in_dtype == 0 ? 16 : 13;
+    return 1;
+}
+
+// Name of the kernel template an explicit algo id launches (rocprofv3 kernel-trace names start with it).
+const char* algo_kernel_name(int algo, int D)
+{
+    switch (algo) {
+        case 1: return "fa::fa_fwd_generic_kernel";
+        case 2: return (D == 64 || D == 128) ? "fa::fa_fwd_kernel" : "fa::fa_fwd_generic_kernel";
+        case 5: case 6: return "fa::fa_fwd_il_kernel";
+        case 13: return "fa::fa_fwd_w64_kernel";
+        case 16: return "fa::fa_fwd_w64x_kernel";
+        case 21: case 22: return "fa::fa_fwd_rp_kernel";
+        default: return "";
+    }
+}
+
 // algo: 0 auto, 1 generic single-fragment kernel, 2 tiled kernel (D in {64,128} only),
 //       3 software-pipelined tiled kernel (D = 64 only), 4 ping-pong tiled kernel (D in {64,128})
 hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O,
@@ -510,31 +545,15 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     // per-head byte offsets are 32 bit, including the rows a partial last query block overhangs
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
-    if (algo == 0 && D == 64) {
-        // d = 64: 64 query rows per wave in 512-row workgroups, on 16x16x32 MFMAs (fa_fwd_w64x.hip), when there is at least one per CU
-        // at least twice over; else the interleaved kernel with 256-row workgroups, or 128-row ones
-        // (two per CU) for twice the parallelism.
-        const long long nwg512 = (long long)BH * ((N + 511) / 512);
-        // fp16 on 16x16x32 MFMAs (w64x), bf16 on 32x32x16 (w64): bf16 draws less power, holds a higher clock and is
-        // decided by cycle count (w64: 3 % fewer), fp16 by energy (w64x: -2...-5 % wall) -- measured on five devices
-        // (one 512-row workgroup per CU is already enough: B2 H16 N4096 0.141 vs 0.150 ms, B4 H16 N2048 0.083 vs 0.086 for the
-        // interleaved kernel; at half a workgroup per CU -- B1 H16 N4096 -- the smaller workgroups win 0.088 vs 0.141)
-        if (nwg512 >= 256)
-            return in_dtype == 0 ? w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream)
-                                 : w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-        const long long nwg256 = (long long)BH * ((N + 255) / 256);
-        return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, nwg256 >= 512 ? 8 : 4, stream);
-    }
-    // d = 128: the same stream with two 16-row blocks per wave (fa_fwd_w64x.hip; 256-row workgroups)
-    if (algo == 0 && D == 128) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    if (algo == 0) algo = auto_algo(BH, N, D, in_dtype);
+    if (algo == 5) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 8, stream);
+    if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 21) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 22) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
-    if (algo == 17) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
-    if (algo == 18) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);   // exact pass only
 #ifdef FA_EXPERIMENTS
-    if (algo == 19 || algo == 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
+    if (algo >= 17 && algo <= 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 7 || algo == 8) {   // occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out
@@ -549,10 +568,8 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
 #else
-    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 12) || algo == 14 || algo == 15 || algo == 19 || algo == 20 || algo > 22) return hipErrorInvalidValue;
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 12) || algo == 14 || algo == 15 || (algo >= 17 && algo <= 20) || algo > 22) return hipErrorInvalidValue;
 #endif
-    if (algo == 5) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 8, stream);
-    if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
                               : dispatch_d<F16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);

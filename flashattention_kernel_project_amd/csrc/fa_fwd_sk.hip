@@ -466,7 +466,6 @@ hipError_t sk_dispatch(const void* Q, const void* K, const void* V, void* O,
     if (D != 64) return hipErrorInvalidValue;
     if ((unsigned long long)(N + 64 * sk::kW) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (!(scale == scale) || scale * kLog2e == 0.0f) variant |= 1;   // NaN / zero scale: the exact pass defines the result
-#ifdef FA_EXPERIMENTS
 #define SK_GO(T, OUT, FOLD, SKEW) return launch_sk<T, 64, 2, OUT, FOLD, SKEW>(Q, K, V, O, BH, N, scale, stream)
     if (in_dtype == 0) {
         if (out_dtype == 0) {
@@ -484,17 +483,6 @@ hipError_t sk_dispatch(const void* Q, const void* K, const void* V, void* O,
     }
     SK_GO(BF16, false, false, true);
 #undef SK_GO
-#else
-    if (in_dtype == 0) {
-        if (variant & 1)
-            return out_dtype == 0 ? launch_sk<F16, 64, 2, true, false, true>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_sk<F16, 64, 2, false, false, true>(Q, K, V, O, BH, N, scale, stream);
-        return out_dtype == 0 ? launch_sk<F16, 64, 2, true, true, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_sk<F16, 64, 2, false, true, true>(Q, K, V, O, BH, N, scale, stream);
-    }
-    return out_dtype == 0 ? launch_sk<BF16, 64, 2, true, false, true>(Q, K, V, O, BH, N, scale, stream)
-                          : launch_sk<BF16, 64, 2, false, false, true>(Q, K, V, O, BH, N, scale, stream);
-#endif
 }
 
 }  // namespace fa

@@ -283,7 +283,7 @@ void fa_fwd_w64m_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     run(no);
     float l_row[X];
     bool bad = false;
-    const float lim = T::id == 1 ? INFINITY : 60000.0f;   // a packed p can only have overflowed if the row sum got here
+    const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;   // a packed p can only have overflowed if the row sum got here
 #pragma unroll
     for (int x = 0; x < X; ++x) {
         l_row[x] = l_part[x] + swap_halves(l_part[x]);

@@ -421,7 +421,7 @@ void fa_fwd_w64p_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     float l_row[X];
     bool bad = false;
     // a packed p can only have overflowed if the fp32 row sum reached the 16-bit format's range
-    const float lim = T::id == 1 ? INFINITY : 60000.0f;
+    const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
 #pragma unroll
     for (int x = 0; x < X; ++x) {
         l_row[x] = l_part[x] + swap_halves(l_part[x]);

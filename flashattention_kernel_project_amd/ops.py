@@ -87,10 +87,13 @@ def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = 
         scale = 1.0 / math.sqrt(d)
     dts = (torch.float16, torch.bfloat16)
     fn_name = "fa_forward_causal" if causal else "fa_forward_ex"
-    code = getattr(capi.lib(), fn_name)(
-        _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts),
-        _dev_ptr(out, "out", (out_dtype,)), B, H, N, d, float(scale), in_dt, out_dt, algo,
-        _stream_ptr(stream))
+    if not (q.device == k.device == v.device == out.device):
+        raise ValueError("q, k, v and out must live on one device")
+    with torch.cuda.device(q.device):   # the launch goes to the CURRENT device: make that the tensors' device
+        code = getattr(capi.lib(), fn_name)(
+            _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts),
+            _dev_ptr(out, "out", (out_dtype,)), B, H, N, d, float(scale), in_dt, out_dt, algo,
+            _stream_ptr(stream))
     capi.check(fn_name, code)
     return out
 

@@ -29,21 +29,29 @@ extern "C" {
 #define FA_OUT_F32    0   /* the reference's output type */
 #define FA_OUT_SAME   1   /* output in the input's 16-bit type */
 
-#define FA_ALGO_AUTO            0 /* d=64: W64X for fp16, W64 for bf16 (INTERLEAVED / _2WG when the grid is small); d=128: W64X; else GENERIC */
+/* Kernel selection for fa_forward_ex().  Ids present in the product library: */
+#define FA_ALGO_AUTO            0 /* d=64: RP_FOLD for fp16 / RP for bf16 (INTERLEAVED / _2WG when the grid is smaller than one 512-row
+                                     workgroup per CU); d=128: W64X for fp16, W64 for bf16; else GENERIC -- fa_selected_algo() */
 #define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
-#define FA_ALGO_PIPE            3 /* the same with QK^T of tile t+1 under the softmax of tile t, D = 64 */
-#define FA_ALGO_PINGPONG        4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
 #define FA_ALGO_INTERLEAVED     5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
 #define FA_ALGO_INTERLEAVED_2WG 6 /* the same with 128-row workgroups, two per CU, D = 64 */
+#define FA_ALGO_W64            13 /* 64 query rows per wave (d=64) / 32 (d=128), phase-ordered stream on 32x32x16, persistent grid */
+#define FA_ALGO_W64X           16 /* the W64 stream on v_mfma_f32_16x16x32: four (d=64) / two (d=128) 16-row blocks per wave share every fragment */
+#define FA_ALGO_RP             21 /* rolling half-tile pipeline, branch-free steady state, single-instruction fp32 vector work, D in {64,128} */
+#define FA_ALGO_RP_FOLD        22 /* RP with the folded fast pass (scale folded into a rounded Q, wave reference max as accumulator
+                                     start; exact tracked pass as fallback), fp16 at D = 64; other inputs run RP */
+/* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
+ * A/B kernels that AUTO never selects. */
+#define FA_ALGO_PIPE            3 /* TILED with QK^T of tile t+1 under the softmax of tile t, D = 64 */
+#define FA_ALGO_PINGPONG        4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
 #define FA_ALGO_TLP3            9 /* simple per-wave stream, three 128-row workgroups per CU, D = 64 */
 #define FA_ALGO_IL16           11 /* 16 waves x 16 rows on v_mfma_f32_16x16x32, D = 64 */
 #define FA_ALGO_IL2X16         12 /* 8 waves x two 16-row blocks sharing K/V fragments, 16x16x32, D = 64 */
-#define FA_ALGO_W64            13 /* 64 query rows per wave (d=64) / 32 (d=128), phase-ordered stream, persistent grid */
-#define FA_ALGO_W64P           14 /* the same with a half-tile rolling pipeline, D in {64,128} */
-#define FA_ALGO_W64M           15 /* W64 with QK^T one tile ahead, merged with PV into one matrix phase (slower; A/B only) */
-#define FA_ALGO_W64X           16 /* the W64 stream on v_mfma_f32_16x16x32: four (d=64) / two (d=128) 16-row blocks per wave share every fragment */
-/* 7, 8, 10: experimental occupancy variants kept for A/B timing (fp16, d=64). */
+#define FA_ALGO_W64P           14 /* W64 with a half-tile rolling pipeline, packed fp32 (round 1's form of RP), D in {64,128} */
+#define FA_ALGO_W64M           15 /* W64 with QK^T one tile ahead, merged with PV into one matrix phase */
+#define FA_ALGO_SK             17 /* skewed halves: waves 4-7 half an iteration behind waves 0-3, folded fast pass; 18 exact, 19/20 lock-step */
+/* 7, 8, 10: occupancy variants of TILED (fp16, d=64). */
 
 /* General-shape forward.  Replaces
  *   flashattn_forward_wmma_kernel(const half* Q, const half* K, const half* V, float* O,
@@ -121,6 +129,12 @@ int flashattn_streaming_16x16_mw_kt(const void* Q, const void* K_T, const void* 
 
 /* Library identification: "fa_mi355 <version> gfx950". */
 const char* fa_mi355_version(void);
+
+/* What FA_ALGO_AUTO resolves to for a shape on the CURRENT device (an FA_ALGO_* id; -1 for bad arguments), and the
+ * name of the kernel template an algo id launches there (prefix of its rocprofv3 kernel-trace name; "" if unknown).
+ * bench.py names its dominant kernel with these instead of hard-coding it. */
+int fa_selected_algo(int B, int H, int N, int d, int in_dtype);
+const char* fa_selected_kernel(int B, int H, int N, int d, int in_dtype, int algo);
 
 /* 1 when the library was built with the experimental A/B kernels (`make experimental`: explicit algo ids
  * 3, 4, 7-12, 14, 15 and the measurement entry points), 0 for the product build, where those ids return

@@ -40,7 +40,7 @@ def _run(fa, torch, qb, kb, vb, fmt, algo=0, out_same=False, scale=None):
     return o.float().cpu().numpy()
 
 
-_EXPERIMENTAL = (3, 4, 7, 8, 9, 10, 11, 12, 14, 15)   # A/B kernels: only in libfa_mi355_exp.so (FA_MI355_LIB=...)
+_EXPERIMENTAL = (3, 4, 7, 8, 9, 10, 11, 12, 14, 15, 17, 18, 19, 20)   # A/B kernels: only in libfa_mi355_exp.so (FA_MI355_LIB=...)
 
 
 def _have_exp():
@@ -49,7 +49,8 @@ def _have_exp():
 
 
 def _algos_for(d):
-    algos = (0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16) if d == 64 else ((0, 1, 2, 4, 13, 14, 15, 16) if d == 128 else (0, 1))
+    algos = ((0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22) if d == 64
+             else ((0, 1, 2, 4, 13, 14, 15, 16, 21) if d == 128 else (0, 1)))
     return tuple(a for a in algos if a not in _EXPERIMENTAL or _have_exp())
 
 
@@ -299,7 +300,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     # 13, 14) sum the ROUNDED bf16 weights instead and meet the plain bar; the A/B variants do not.
     def tol(algo):
         return MAX_ABS * (2.0 if fmt == 1 and algo in (9, 11, 12) else 1.0)
-    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) if a not in _EXPERIMENTAL or _have_exp()):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol(algo))
     # ragged N with the overflow in the partial last tile
@@ -308,7 +309,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     k2[0, n2 - 1] = q2[0, 200] * 40.0
     q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
     want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
-    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) if a not in _EXPERIMENTAL or _have_exp()):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
         _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol(algo))
 
@@ -572,3 +573,181 @@ def test_splitkv_grouped_query_heads(fa, oracle, torch_cuda):
     got = fa.fa_forward_splitkv(_to_dev(torch, qb, 0).view(b, hq, nq, d), dk, dv)
     torch.cuda.synchronize()
     _check(oracle, got.view(b * hq, nq, d).float().cpu().numpy(), want, 0, "splitkv GQA nq=5")
+
+
+# ---------------------------------------------------------------- round 2: configs at their stated shapes, AUTO edges, the folded pass
+
+def _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, rows, what):
+    """q,k,v,o: [B,H,N,d] device tensors; rows: list of (b, h, r0, n) row ranges checked against the oracle."""
+    for (b, h, r0, n) in rows:
+        qs, ks, vs = (t[b, h].float().cpu().numpy()[None] for t in (q, k, v))
+        want = oracle.forward(qs, ks, vs, accum=0, nthreads=8, row_range=(r0, r0 + n))
+        _check(oracle, o[b, h, r0:r0 + n].float().cpu().numpy(), want[0, r0:r0 + n], fmt, f"{what} b={b} h={h} rows {r0}..{r0 + n}")
+
+
+def test_cfg3_exact_shape_through_auto(fa, oracle, torch_cuda):
+    """BASELINE config 3 at its stated shape, B=4 H=8 N=1024 d=64 fp16, through FA_ALGO_AUTO (the small-grid branch),
+    every row of every head against the oracle (8.6 GFLOP on the CPU)."""
+    torch = torch_cuda
+    (q, k, v), (qb, kb, vb) = oracle.make_qkv(32, 1024, 64, 0, seed=303)
+    sel = fa.lib().fa_selected_algo(4, 8, 1024, 64, 0)
+    assert sel in (5, 6), sel
+    Q, K, V = (_to_dev(torch, x, 0).view(4, 8, 1024, 64) for x in (qb, kb, vb))
+    o = fa.fa_forward(Q, K, V)
+    torch.cuda.synchronize()
+    want = oracle.forward(q, k, v, accum=0, nthreads=16)
+    _check(oracle, o.view(32, 1024, 64).cpu().numpy(), want, 0, "cfg3 B4 H8 N1024 d64 fp16 AUTO")
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_cfg5_per_gpu_full_size(fa, oracle, torch_cuda, fmt):
+    """BASELINE config 5, one GPU's shard at full size: B=8 H=16 N=8192 d=128.  Sampled row blocks against the oracle,
+    plus the size-independent properties: every output inside its head's V range (convexity), constant V -> constant O."""
+    torch = torch_cuda
+    dt = _tdtype(torch, fmt)
+    g = torch.Generator(device="cuda").manual_seed(55 + fmt)
+    q, k, v = (torch.randn(8, 16, 8192, 128, generator=g, device="cuda").to(dt) for _ in range(3))
+    o = fa.fa_forward(q, k, v)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(o).all())
+    _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, [(0, 0, 0, 16), (7, 15, 8176, 16), (3, 9, 4090, 16), (5, 2, 6000, 8)], "cfg5")
+    vmin = v.float().amin(dim=2, keepdim=True)
+    vmax = v.float().amax(dim=2, keepdim=True)
+    assert bool(((o >= vmin - 2e-3) & (o <= vmax + 2e-3)).all())
+    vc = torch.full_like(v[:1], 0.5)
+    oc = fa.fa_forward(q[:1], k[:1], vc)
+    assert float((oc - 0.5).abs().max()) <= 4e-3
+    del q, k, v, o, oc
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_auto_dispatch_boundaries(fa, oracle, torch_cuda, fmt):
+    """FA_ALGO_AUTO at d=64 switches kernels where the grid reaches one 512-row workgroup per CU and two 256-row
+    workgroups per CU: one shape on each side of both thresholds, through algo 0, against the oracle."""
+    torch = torch_cuda
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    L = fa.lib()
+    big = 21 if fmt == 1 else 22
+    for (bh, n, want_algo) in [(cus - 1, 512, 6), (cus, 512, big), (2 * cus - 1, 256, 6), (2 * cus, 256, 5), (cus, 500, big), (cus // 2, 513, big), (4 * cus, 250, 5)]:
+        sel = L.fa_selected_algo(bh, 1, n, 64, fmt)
+        if want_algo is not None:
+            assert sel == want_algo, (bh, n, sel)
+        assert L.fa_selected_kernel(bh, 1, n, 64, fmt, 0).decode().startswith("fa::fa_fwd_")
+        (q, k, v), (qb, kb, vb) = oracle.make_qkv(bh, n, 64, fmt, seed=900 + bh + n)
+        got = _run(fa, torch, qb, kb, vb, fmt)
+        heads = sorted({0, bh // 2, bh - 1})
+        want = oracle.forward(q[heads], k[heads], v[heads], accum=0, nthreads=16)
+        _check(oracle, got[heads], want, fmt, f"AUTO boundary bh={bh} n={n} fmt={fmt} -> algo {sel}")
+
+
+def test_bf16_overflow_window_below_inf(fa, oracle, torch_cuda):
+    """bf16 keeps p finite up to 2^127, so a late score 120..127 log2 units above the reference leaves the row SUM finite
+    while sum(p*v) overflows fp32 at |V| ~ 4: the optimistic pass must still be rejected (finite limit 2^96)."""
+    n, d, bh, fmt = 640, 64, 2, 1
+    (q, k, v), _ = oracle.make_qkv(bh, n, d, fmt, seed=4321)
+    v *= 4.0
+    ln2 = float(np.log(2.0))
+    for (b, qi, key, lift) in [(0, 9, 500, 122.0), (0, 200, 639, 126.5), (1, 64, 70, 110.0), (1, 300, 300, 97.0)]:
+        s0 = (q[b, qi] @ k[b, :64].T) / np.sqrt(d)
+        target = (s0.max() + lift * ln2) * np.sqrt(d)
+        k[b, key] = q[b, qi] * (target / float(q[b, qi] @ q[b, qi]))
+    q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
+    qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
+    want = oracle.forward(q, k, v, accum=1, nthreads=8)
+    for algo in (a for a in (0, 5, 6, 13, 16, 21, 14, 17) if a not in _EXPERIMENTAL or _have_exp()):
+        got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
+        _check(oracle, got, want, fmt, f"bf16 window algo={algo}", max_abs=4 * MAX_ABS)   # |V| = 4 x the N(0,1) bar
+
+
+def test_folded_pass_gates(fa, oracle, torch_cuda):
+    """The fp16 fast pass of FA_ALGO_RP_FOLD (scale folded into a rounded Q, one reference maximum per wave) must hand a
+    workgroup to the exact pass whenever its assumptions fail, and agree with the exact kernel where they hold."""
+    d, fmt = 64, 0
+    cases = []
+    # (a) rows of one wave with very different maxima: the wave reference sits far above some rows' scores
+    (q, k, v), _ = oracle.make_qkv(2, 576, d, fmt, seed=61)
+    q[0, 0:32] *= 8.0
+    q[0, 32:64] *= 0.02
+    k[0, 5] = q[0, 3] * 3.0
+    cases.append(("mixed row maxima", q, k, v, None))
+    # (b) large logits everywhere (reference max beyond kFoldMax)
+    (q, k, v), _ = oracle.make_qkv(2, 320, d, fmt, seed=62)
+    cases.append(("large logits", q * 6.0, k * 6.0, v, None))
+    # (c) Q*scale below fp16's normal range, K large enough that the logits still matter
+    (q, k, v), _ = oracle.make_qkv(1, 256, d, fmt, seed=63)
+    cases.append(("tiny folded Q", q * 1e-3, k * 50.0, v, 0.02))
+    # (d) Q*scale overflowing fp16
+    (q, k, v), _ = oracle.make_qkv(1, 256, d, fmt, seed=64)
+    cases.append(("overflowing folded Q", q * 200.0, k * 1e-2, v, 300.0))
+    # (e) negative scale, ragged N, one key only
+    (q, k, v), _ = oracle.make_qkv(3, 333, d, fmt, seed=65)
+    cases.append(("negative scale", q, k, v, -0.2))
+    (q, k, v), _ = oracle.make_qkv(2, 1, d, fmt, seed=66)
+    cases.append(("one key", q, k, v, None))
+    # (f) all scores far below zero against a few near it (row sums below the lower gate)
+    (q, k, v), _ = oracle.make_qkv(1, 2048, d, fmt, seed=67)
+    k[0, 64:] = -np.abs(k[0, 64:]) * 3.0
+    q[0] = np.abs(q[0])
+    cases.append(("late keys all far below", q, k, v, None))
+    for (name, q, k, v, scale) in cases:
+        q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
+        qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
+        want = oracle.forward(q, k, v, accum=1, nthreads=8, **({} if scale is None else {"scale": scale}))
+        for algo in (22, 21, 0):
+            got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo, scale=scale)
+            _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo}")
+
+
+def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda):
+    """N(0,1) inputs at the bench shape: the folded pass is taken (no gate fires) and its output stays within the
+    tolerance of the exact pass on every element."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q, k, v = (torch.randn(2, 16, 4096, 64, generator=g, device="cuda").half() for _ in range(3))
+    a = fa.fa_forward(q, k, v, algo=22)
+    b = fa.fa_forward(q, k, v, algo=21)
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max()) <= 2e-3
+    _sampled_rows_check(fa, oracle, torch, q, k, v, a, 0, [(0, 0, 0, 32), (1, 15, 4064, 32), (1, 7, 2000, 16)], "folded pass")
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 path on ONE device: two ranks started by torch.distributed.run, gloo for the barrier and the
+    max-reduction (the driver's own runs use RCCL), exactly one JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FA_BENCH_BACKEND="gloo", FA_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--sustained", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+
+
+def test_native_harness_check_step():
+    """bench/fa_bench --check: the reference driver's sequence in the native harness (CPU reference, one check launch,
+    rel-L2 and max-abs print, then the timed loop) for both families; the error figures are parsed from its output."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bench", "fa_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "bench")])
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "liboracle_cpu.so"], stdout=subprocess.DEVNULL)
+    for args, tol_abs, tol_rel in ((["--family", "s16", "--B", "1024", "--N", "128", "--check", "--iters", "5", "--warmup", "2"], 1e-2, 2e-3),
+                                   (["--B", "2", "--H", "4", "--N", "512", "--d", "64", "--check", "--iters", "5", "--warmup", "2"], 1e-2, 2e-3),
+                                   (["--B", "1", "--H", "2", "--N", "300", "--d", "128", "--dtype", "bf16", "--out", "same", "--check", "--iters", "3", "--warmup", "1"], 3e-2, 1.5e-2)):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        m = re.search(r"rel_l2 = ([0-9.eE+-]+)\s+max_abs = ([0-9.eE+-]+)", out.stdout)
+        assert m, out.stdout
+        rel, mab = float(m.group(1)), float(m.group(2))
+        assert rel <= tol_rel and mab <= tol_abs, (args, rel, mab)
+        assert "TFLOPS" in out.stdout
