@@ -483,6 +483,9 @@ hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
 hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream);
+hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
+                         int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
+                         hipStream_t stream);
 hipError_t rp_dispatch(const void* Q, const void* K, const void* V, void* O,
                        int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
                        hipStream_t stream);
@@ -500,9 +503,10 @@ hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
                            hipStream_t stream);
 
 // AUTO: the explicit algo id a shape resolves to (one rule for the dispatcher and for fa_selected_kernel()).
-//   d = 64, N > 256 and at least one 512-row workgroup per CU: the rolling half-tile pipeline (fa_fwd_rp.hip), with the folded fast
-//     pass for fp16 (22) and the exact pass for bf16 (21) -- round 2, same device, sustained: fp16 0.542 vs 0.554 ms for
-//     fa_fwd_w64x, bf16 0.539 vs 0.547 for fa_fwd_w64;
+//   d = 64, N > 256 and at least one 512-row workgroup per CU: the rolling half-tile pipeline -- fp16 on 16x16x32 with the
+//     folded fast pass (fa_fwd_rp16.hip, 24), bf16 on 32x32x16 with the exact pass (fa_fwd_rp.hip, 21).  Round 2, one device,
+//     interleaved A/B: fp16 0.500 ms (24) / 0.524 (22, the same on 32x32x16) / 0.526 (23) / 0.541 (fa_fwd_w64x);
+//     bf16 0.522 (21) / 0.530 (23) / 0.532 (fa_fwd_w64);
 //   d = 64, smaller grids: the interleaved kernel with 256-row workgroups, or 128-row ones (two per CU);
 //   d = 128: fa_fwd_w64x for fp16 (3.86 vs 4.04 ms at N 8192), fa_fwd_w64 for bf16 (3.78 vs 3.92 ms);
 //   anything else: the generic single-fragment kernel.
@@ -512,7 +516,7 @@ int auto_algo(int BH, int N, int D, int in_dtype)
     if (D == 64) {
         const long long cus = device_cus();
         const long long nwg512 = (long long)BH * ((N + 511) / 512);
-        if (N > 256 && nwg512 >= cus) return in_dtype == 0 ? 22 : 21;   // N <= 256 would leave half of every 512-row workgroup idle
+        if (N > 256 && nwg512 >= cus) return in_dtype == 0 ? 24 : 21;   // N <= 256 would leave half of every 512-row workgroup idle
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return nwg256 >= 2 * cus ? 5 : 6;
     }
@@ -530,6 +534,7 @@ const char* algo_kernel_name(int algo, int D)
         case 13: return "fa::fa_fwd_w64_kernel";
         case 16: return "fa::fa_fwd_w64x_kernel";
         case 21: case 22: return "fa::fa_fwd_rp_kernel";
+        case 23: case 24: return "fa::fa_fwd_rp16_kernel";
         default: return "";
     }
 }
@@ -552,6 +557,8 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 21) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 22) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
+    if (algo == 23) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
+    if (algo == 24) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
 #ifdef FA_EXPERIMENTS
     if (algo >= 17 && algo <= 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
@@ -568,7 +575,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
 #else
-    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 12) || algo == 14 || algo == 15 || (algo >= 17 && algo <= 20) || algo > 22) return hipErrorInvalidValue;
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 12) || algo == 14 || algo == 15 || (algo >= 17 && algo <= 20) || algo > 24) return hipErrorInvalidValue;
 #endif
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)

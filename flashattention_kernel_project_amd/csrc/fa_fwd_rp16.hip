@@ -1,0 +1,513 @@
+// fa_fwd_rp16.hip -- the rolling half-tile pipeline of fa_fwd_rp.hip on v_mfma_f32_16x16x32 (d = 64).
+//
+// Why a second shape of the same stream: the d=64 forward runs at the package power cap, where wall time is joules per
+// launch divided by the cap (fa_fwd_rp needs 15 % fewer cycles than fa_fwd_w64x and lands at the same
+// 0.55 ms, the clock simply settles at 1.80 instead of 2.10 GHz).  Sustained at two waves per SIMD the slot model
+// (tools/slot_energy.py, profiles/r02_slot_energy.txt) prices one slot -- two scores per lane -- at
+//     32x32x16 + folded vector work      21.7 nJ per SIMD     2 x 16x16x32 + folded      19.6 nJ   (-9 %)
+//     32x32x16 + exact vector work       25.7 nJ              2 x 16x16x32 + exact       23.4 nJ   (-9 %)
+// although the 16x16x32 form needs a quarter more cycles per slot (it holds the issue port 8 of every 16 cycles).
+// So: the same pipeline (QK^T one half tile ahead, PV one behind, the softmax of the half tile in between issued as
+// slices between the matrix instructions, branch-free steady state, folded fast pass with the wave reference maximum as
+// the accumulators' start value) with the lane roles and LDS images of fa_fwd_w64x.hip:
+//   lane = 16 g + c; the accumulator of S^T = K.Q^T for (16-row query block x, 16-key block kb) holds query 16x + c on
+//   the lane and keys 16kb + 4g + i in register i; the packed registers of key blocks 2s, 2s+1 are the B fragment of
+//   k-step s of O^T += V^T.P^T; K row-major with the 16-B chunk index XORed by (row >> 1) & 7, V in 256-B blocks
+//   [key/8][d/16] x [8 keys][16 cols] for ds_read_b64_tr_b16.
+// A step = one half tile (32 keys) = 32 matrix instructions (16 QK^T + 16 PV, four K and four V^T fragments, each
+// feeding the wave's four query blocks) around the vector work of 32 scores per lane.
+#include "fa_tile.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace fa {
+
+namespace rp16 {
+template <int... I, typename F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+template <typename T> struct Mx;
+template <> struct Mx<F16> {
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mx<BF16> {
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+constexpr int kW = 8, X = 4, D = 64;
+#ifndef FA_RP16_AHEAD
+#define FA_RP16_AHEAD 2
+#endif
+constexpr int kAhead = FA_RP16_AHEAD;   // fragments read ahead of their MFMAs (at most kRing - 1)
+constexpr int kRing = 4;           // fragment registers (8 fragments per step)
+constexpr float kHeadroom = 4.0f;
+constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
+#ifndef FA_RP16_STAGE_SLOT
+#define FA_RP16_STAGE_SLOT 16      // matrix slot of the second step in front of which tile j+2 is written to LDS
+#endif
+}  // namespace rp16
+
+template <typename T, bool kOutF32, bool kFold>
+__global__ __launch_bounds__(64 * rp16::kW, 2)
+void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
+                        const uint16_t* __restrict__ Vg, void* __restrict__ Og,
+                        int N, int nqb, float scale_log2e, unsigned total_wg)
+{
+    using namespace rp16;
+    using M = Mx<T>;
+    using G = TileGeom<D>;
+    static_assert(!kFold || T::id == 0, "the folded pass rounds Q*scale to fp16");
+    constexpr int kRows = 16 * X * kW;
+    constexpr int kKS = D / 32, kDB = D / 16;   // k-steps of QK^T (2), 16-row blocks of O^T (4)
+    constexpr unsigned kRowB = D * 2;
+    constexpr unsigned kTile = kBlockN * D * 2;
+    constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of four slots
+
+    const unsigned tid  = threadIdx.x;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane = tid & 63u;
+    const unsigned c16 = lane & 15u, g = lane >> 4;
+    const float c = fabsf(scale_log2e);
+    const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
+    const int ntiles = (N + kBlockN - 1) / kBlockN;
+    const bool partial = (N % kBlockN) != 0;
+
+    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
+    const unsigned st_goff = srow * kRowB + sch * 16u;
+    const unsigned k_lds = G::k_off(srow, sch);
+    const unsigned v_lds = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
+    unsigned k_rd[kKS];
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) k_rd[ks] = c16 * kRowB + (((4u * ks + g) ^ G::k_swz(c16)) << 4);
+    const unsigned v_rd = kTile + (g >> 1) * (unsigned)kDB * 256u + ((4u * (g & 1u) + (c16 >> 2)) << 5) + (c16 & 3u) * 8u;
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero4u = {0u, 0u, 0u, 0u};
+    const std::true_type yes{};
+    const std::false_type no{};
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    auto across_max = [&](float v) -> float {   // over the four lanes that share a query row
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        return fmaxf(v, __shfl_xor(v, 32, 64));
+    };
+    auto across_sum = [&](float v) -> float {
+        v += __shfl_xor(v, 16, 64);
+        return v + __shfl_xor(v, 32, 64);
+    };
+
+    const unsigned nwg = total_wg;
+    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    if (bid != blockIdx.x) __syncthreads();
+    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
+    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const unsigned bh = wgid / (unsigned)nqb;
+    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const size_t head_elems = (size_t)N * D;
+    const unsigned head_bytes = (unsigned)(head_elems * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+    const unsigned q_row0 = qb * kRows + wave * (16u * X) + c16;   // row of block 0; block x is 16x rows further
+
+    u32x4 qf[X][kKS];   // B operand of QK^T: Q[row of block x][32 ks + 8 g .. +7]
+    int q_bad = 0;
+    auto load_q = [&](auto fold_c) __attribute__((always_inline)) {
+        constexpr bool fold = decltype(fold_c)::value;
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            float amax = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                u32x4 raw = buf_load16(rq, (q_row0 + 16u * x) * kRowB + (32u * ks + 8u * g) * 2u);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if constexpr (fold) {
+                        const float lo = T::lo(raw[w]) * scale_log2e, hi = T::hi(raw[w]) * scale_log2e;
+                        amax = max3(amax, fabsf(lo), fabsf(hi));
+                        raw[w] = T::pack2(lo, hi);
+                    } else {
+                        raw[w] ^= q_flip;
+                    }
+                }
+                qf[x][ks] = raw;
+            }
+            if constexpr (fold) q_bad |= (int)!(amax <= 65504.0f) | ((int)(amax != 0.0f) & (int)(amax < 6.2e-5f));
+        }
+    };
+
+    f32x4 o[X][kDB];
+    float m_ref[X] = {}, l_part[X] = {};
+    u32x4 kst, vst;
+    u32x4 frag[kRing];
+    f32x4 minit;   // folded pass: every score chain starts at -(wave reference maximum)
+
+    // K fragment (key block kbl of half h in slot offset so, k-step ks); V^T fragment (head-dim block db) of half h
+    auto read_kf = [&](unsigned so, int h, int kbl, int ks) -> u32x4 {
+        return lds_read16(smem, so + (unsigned)(2 * h + kbl) * 16u * kRowB + k_rd[ks]);
+    };
+    auto read_vf = [&](unsigned so, int h, int db) -> u32x4 {
+        u32x4 vf;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const u32x2 half = lds_read_tr8(smem, so + v_rd + (4u * h + 2u * jj) * (unsigned)kDB * 256u + db * 256u);
+            vf[2 * jj] = half[0];
+            vf[2 * jj + 1] = half[1];
+        }
+        return vf;
+    };
+    // fragment f (0..7) of a step: even f -> K fragment (kbl = f/4, ks = (f/2)&1) of the QK^T unit, odd f -> V^T fragment
+    // db = f/2 of the PV unit
+    auto read_frag = [&](auto fc, unsigned so_q, int h_q, unsigned so_v, int h_v) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, h_q, f >> 2, (f >> 1) & 1);
+        else frag[f % kRing] = read_vf(so_v, h_v, f >> 1);
+    };
+    auto mask_unit = [&](int tile, int h, f32x4 (&s)[X][2]) {   // keys >= N -> -inf (p = 0)
+#pragma unroll
+        for (int x = 0; x < X; ++x)
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (tile * kBlockN + 32 * h + 16 * kbl + 4 * (int)g + i >= N) s[x][kbl][i] = -INFINITY;
+    };
+    auto row_max = [&](const f32x4 (&s)[2]) -> float {   // this row's 32 keys of the unit, unscaled
+        const float a = max3(s[0][0], s[0][1], s[0][2]), b = max3(s[1][0], s[1][1], s[1][2]);
+        return across_max(max3(a, b, fmaxf(s[0][3], s[1][3])));
+    };
+
+    // One step of an optimistic pass.  h = half of tile `tile` being softmaxed (s_cur -> pk_cur); the QK^T unit is
+    // (so_q, 1-h) -> s_nxt, the PV unit (so_v, 1-h) <- pk_prev.  so_nq / so_nv: slots of the NEXT step's units.
+    auto step = [&](auto h_c, auto masked_c, auto fast_c, int tile, f32x4 (&s_cur)[X][2], f32x4 (&s_nxt)[X][2],
+                    u32x4 (&pk_prev)[X], u32x4 (&pk_cur)[X], unsigned so_q, unsigned so_v, unsigned so_nq, unsigned so_nv,
+                    unsigned so_land) __attribute__((always_inline)) {
+        constexpr int h = decltype(h_c)::value, ho = 1 - h;
+        constexpr bool kFast = decltype(fast_c)::value;
+        if constexpr (decltype(masked_c)::value) mask_unit(tile, h, s_cur);
+
+        constexpr int kPairs = 4 * X;   // vector pair-steps: pair j = (block j/4, key block (j/2)&1, registers 2(j&1), 2(j&1)+1)
+        float ls[X][2];
+#pragma unroll
+        for (int x = 0; x < X; ++x) ls[x][0] = ls[x][1] = 0.0f;
+        auto fma_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
+            s_cur[x][kbl][e] = __builtin_fmaf(s_cur[x][kbl][e], c, -m_ref[x]);
+            s_cur[x][kbl][e + 1] = __builtin_fmaf(s_cur[x][kbl][e + 1], c, -m_ref[x]);
+        };
+        auto exp_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
+            s_cur[x][kbl][e] = fast_exp2(s_cur[x][kbl][e]);
+            s_cur[x][kbl][e + 1] = fast_exp2(s_cur[x][kbl][e + 1]);
+        };
+        auto fin_pair = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
+            const unsigned w = T::pack2(s_cur[x][kbl][e], s_cur[x][kbl][e + 1]);
+            pk_cur[x][2 * kbl + (j & 1)] = w;
+            if constexpr (T::kSumRounded) {
+                ls[x][j & 1] = T::sum2(w, ls[x][j & 1]);
+            } else {
+                ls[x][0] += s_cur[x][kbl][e];
+                ls[x][1] += s_cur[x][kbl][e + 1];
+            }
+        };
+        auto valu_step = [&](auto jc) {   // skewed: nothing waits on the instruction before it
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 2 < kPairs && !kFast) fma_pair(std::integral_constant<int, j + 2>{});
+            if constexpr (j + 1 < kPairs) exp_pair(std::integral_constant<int, j + 1>{});
+            fin_pair(jc);
+        };
+        auto issue_mfma = [&](auto ic) {
+            constexpr int i = decltype(ic)::value, f = i / X, x = i % X;
+            if constexpr ((f & 1) == 0) {
+                constexpr int kbl = f >> 2, ks = (f >> 1) & 1;
+                s_nxt[x][kbl] = M::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
+            } else {
+                constexpr int db = f >> 1;
+                o[x][db] = M::mfma(frag[f % kRing], pk_prev[x], o[x][db]);
+            }
+        };
+
+        if constexpr (!kFast) {
+            fma_pair(c0{});
+            fma_pair(c1{});
+        }
+        exp_pair(c0{});
+        sfor<32>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT) {   // land tile j+2 (requested at the top of the iteration)
+                lds_write16(smem, so_land + k_lds, kst);
+                lds_write16(smem, so_land + v_lds, vst);
+            }
+            issue_mfma(ic);
+            if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
+                constexpr int f = i / X + kAhead;
+                if constexpr (f < 8) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
+                else read_frag(std::integral_constant<int, f - 8>{}, so_nq, h, so_nv, h);
+            }
+            if constexpr (i % 2 == 1) valu_step(std::integral_constant<int, i / 2>{});   // one pair-step per two matrix slots
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < X; ++x) l_part[x] += ls[x][0] + ls[x][1];
+    };
+
+    // One step of the tracked (fallback) pass: same data flow in plain program order with the lazy running max.
+    auto step_tracked = [&](auto h_c, int tile, f32x4 (&s_cur)[X][2], f32x4 (&s_nxt)[X][2], u32x4 (&pk_prev)[X],
+                            u32x4 (&pk_cur)[X], unsigned so_q, unsigned so_v, unsigned so_land) __attribute__((always_inline)) {
+        constexpr int h = decltype(h_c)::value, ho = 1 - h;
+#pragma unroll
+        for (int db = 0; db < kDB; ++db) {   // O^T += V(u-1)^T.P(u-1)^T first: P(u-1) is in the scale of the current reference
+            const u32x4 vf = read_vf(so_v, ho, db);
+#pragma unroll
+            for (int x = 0; x < X; ++x) o[x][db] = M::mfma(vf, pk_prev[x], o[x][db]);
+        }
+        if (partial && tile + 1 == ntiles) mask_unit(tile, h, s_cur);
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            const float tmax = row_max(s_cur[x]) * c;
+            if (__any(tmax - m_ref[x] > kThr)) {
+                const float m_new = fmaxf(tmax, m_ref[x]);
+                const float alpha = fast_exp2(m_ref[x] - m_new);
+                m_ref[x] = m_new;
+#pragma unroll
+                for (int db = 0; db < kDB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[x][db][i] *= alpha;
+                l_part[x] *= alpha;
+            }
+            float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float p0 = fast_exp2(fmaf(s_cur[x][kbl][2 * pr], c, -m_ref[x]));
+                    const float p1 = fast_exp2(fmaf(s_cur[x][kbl][2 * pr + 1], c, -m_ref[x]));
+                    const unsigned w = T::pack2(p0, p1);
+                    pk_cur[x][2 * kbl + pr] = w;
+                    if constexpr (T::kSumRounded) {
+                        ls0 = T::sum2(w, ls0);
+                    } else {
+                        ls0 += p0;
+                        ls1 += p1;
+                    }
+                }
+            l_part[x] += ls0 + ls1;
+        }
+#pragma unroll
+        for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                const u32x4 kf = read_kf(so_q, ho, kbl, ks);
+#pragma unroll
+                for (int x = 0; x < X; ++x) s_nxt[x][kbl] = M::mfma(kf, qf[x][ks], ks == 0 ? zero4 : s_nxt[x][kbl]);
+            }
+        if constexpr (h == 1) {
+            lds_write16(smem, so_land + k_lds, kst);
+            lds_write16(smem, so_land + v_lds, vst);
+        }
+    };
+
+    // mode 0: folded fast pass; 1: exact, reference max fixed after the first 32 keys; 2: exact, lazy running max
+    auto run = [&](auto mode_c) __attribute__((always_inline)) {
+        constexpr int kMode = decltype(mode_c)::value;
+        constexpr bool kTrack = kMode == 2, kFast = kMode == 0;
+        const std::integral_constant<bool, kFast> fast_c{};
+        f32x4 sA[X][2], sB[X][2];
+        u32x4 pkA[X], pkB[X];
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+#pragma unroll
+            for (int db = 0; db < kDB; ++db) o[x][db] = zero4;
+            l_part[x] = 0.0f;
+            pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of ring slot 3
+        }
+        // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            kst = buf_load16(rk, (unsigned)pt * kTile + st_goff);
+            vst = buf_load16(rv, (unsigned)pt * kTile + st_goff);
+            if (pt == 0) lds_write16(smem, 3u * kSlotBytes + v_lds, zero4u);
+            lds_write16(smem, (unsigned)pt * kSlotBytes + k_lds, kst);
+            lds_write16(smem, (unsigned)pt * kSlotBytes + v_lds, vst);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kbl = 0; kbl < 2; ++kbl)   // S(unit 0)
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                const u32x4 kf = read_kf(0u, 0, kbl, ks);
+#pragma unroll
+                for (int x = 0; x < X; ++x) sA[x][kbl] = M::mfma(kf, qf[x][ks], ks == 0 ? zero4 : sA[x][kbl]);
+            }
+        {
+            // reference max from the first 32 keys (masked copy when N < 32; the step masks again)
+            f32x4 s0[X][2];
+#pragma unroll
+            for (int x = 0; x < X; ++x) { s0[x][0] = sA[x][0]; s0[x][1] = sA[x][1]; }
+            if (partial && ntiles == 1) mask_unit(0, 0, s0);
+            if constexpr (kFast) {   // one reference for the wave; the folded scores already carry the scale
+                float mw = -INFINITY;
+#pragma unroll
+                for (int x = 0; x < X; ++x) mw = fmaxf(mw, row_max(s0[x]));
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) mw = fmaxf(mw, __shfl_xor(mw, off, 64));
+                mw += kHeadroom;
+#pragma unroll
+                for (int x = 0; x < X; ++x) m_ref[x] = mw;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) minit[i] = -mw;
+#pragma unroll
+                for (int x = 0; x < X; ++x)
+#pragma unroll
+                    for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sA[x][kbl][i] -= mw;   // unit 0 was accumulated from zero
+            } else {
+#pragma unroll
+                for (int x = 0; x < X; ++x) m_ref[x] = row_max(s0[x]) * c + (kTrack ? 0.0f : kHeadroom);
+            }
+        }
+        if constexpr (!kTrack) {   // the first kAhead fragments of the first step: K(tile 0, half 1), V("tile -1")
+            sfor<kAhead>([&](auto fc) { read_frag(fc, 0u, 1, 3u * kSlotBytes, 1); });
+        }
+
+        auto tile_iter = [&](int j, auto masked_c) __attribute__((always_inline)) {
+            const unsigned so_m1 = ((unsigned)(j + 3) & 3u) * kSlotBytes, so_0 = ((unsigned)j & 3u) * kSlotBytes;
+            const unsigned so_p1 = ((unsigned)(j + 1) & 3u) * kSlotBytes, so_p2 = ((unsigned)(j + 2) & 3u) * kSlotBytes;
+            // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
+            kst = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff);
+            vst = buf_load16(rv, (unsigned)(j + 2) * kTile + st_goff);
+            if constexpr (kTrack) {
+                step_tracked(c0{}, j, sA, sB, pkB, pkA, so_0, so_m1, so_p2);
+                step_tracked(c1{}, j, sB, sA, pkA, pkB, so_p1, so_0, so_p2);
+            } else {
+                //   h 0: softmax (j,0);  QK^T (j,1);    PV (j-1,1);  next step: QK^T (j+1,0), PV (j,0)
+                //   h 1: softmax (j,1);  QK^T (j+1,0);  PV (j,0);    next step: QK^T (j+1,1), PV (j,1)
+                step(c0{}, masked_c, fast_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p2);
+                step(c1{}, masked_c, fast_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p2);
+            }
+            __syncthreads();
+        };
+        if constexpr (kTrack) {
+            for (int j = 0; j < ntiles; ++j) tile_iter(j, no);
+        } else {
+            const int nfull = partial ? ntiles - 1 : ntiles;
+            for (int j = 0; j < nfull; ++j) tile_iter(j, no);
+            if (partial) tile_iter(ntiles - 1, yes);
+        }
+        // ---- epilogue: O^T += V(last tile, half 1)^T.P^T ----
+        {
+            const unsigned so = ((unsigned)(ntiles - 1) & 3u) * kSlotBytes;
+#pragma unroll
+            for (int db = 0; db < kDB; ++db) {
+                const u32x4 vf = read_vf(so, 1, db);
+#pragma unroll
+                for (int x = 0; x < X; ++x) o[x][db] = M::mfma(vf, pkB[x], o[x][db]);
+            }
+        }
+    };
+
+    float l_row[X];
+    const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
+    bool bad = false;
+    if constexpr (kFold) {
+        load_q(yes);
+        run(std::integral_constant<int, 0>{});
+        const float lo = (float)N * 0x1p-14f;
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            l_row[x] = across_sum(l_part[x]);
+            bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo) || !(fabsf(m_ref[x]) <= kFoldMax);
+        }
+        bad = bad || q_bad != 0;
+    } else {
+        load_q(no);
+        run(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            l_row[x] = across_sum(l_part[x]);
+            bad = bad || !(l_row[x] < lim);
+        }
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+        if constexpr (kFold) load_q(no);
+        run(std::integral_constant<int, 2>{});
+#pragma unroll
+        for (int x = 0; x < X; ++x) l_row[x] = across_sum(l_part[x]);
+    }
+
+    // o[x][db][i] = O[q_row0 + 16x][16 db + 4 g + i]
+    constexpr unsigned es = kOutF32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t ro =
+        make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
+#pragma unroll
+    for (int x = 0; x < X; ++x) {
+        const float inv = 1.0f / l_row[x];
+        const unsigned row = q_row0 + 16u * x;
+#pragma unroll
+        for (int db = 0; db < kDB; ++db) {
+            const unsigned col = 16u * db + 4u * g;
+            const float a = o[x][db][0] * inv, b = o[x][db][1] * inv, cc = o[x][db][2] * inv, d = o[x][db][3] * inv;
+            if constexpr (kOutF32) {
+                const f32x4 v = {a, b, cc, d};
+                buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+            } else {
+                buf_store8(ro, (row * D + col) * 2u, u32x2{T::pack2(a, b), T::pack2(cc, d)});
+            }
+        }
+    }
+    }   // persistent loop over work items
+}
+
+template <typename T, bool kOutF32, bool kFold>
+static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void* O,
+                              int BH, int N, float scale, hipStream_t stream)
+{
+    using namespace rp16;
+    constexpr int lds_bytes = 4 * 2 * kBlockN * D * 2;   // ring of four [K tile][V tile] slots
+    constexpr int kRows = 16 * X * kW;
+    const int nqb = (N + kRows - 1) / kRows;
+    const long long nwg = (long long)BH * nqb;
+    if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const long long cap = device_cus();
+    const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
+    auto kern = fa_fwd_rp16_kernel<T, kOutF32, kFold>;
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
+    if (attr != hipSuccess) return attr;
+    FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
+              static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb,
+              scale * kLog2e, (unsigned)nwg);
+    return hipGetLastError();
+}
+
+// fold: 1 = folded fast pass (fp16), 0 = exact passes only
+hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
+                         int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
+                         hipStream_t stream)
+{
+    if (D != 64) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * rp16::kW + 3 * kBlockN) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (!(scale == scale) || scale * kLog2e == 0.0f) fold = 0;
+    if (in_dtype == 0 && fold)
+        return out_dtype == 0 ? launch_rp16<F16, true, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<F16, false, true>(Q, K, V, O, BH, N, scale, stream);
+    if (in_dtype == 0)
+        return out_dtype == 0 ? launch_rp16<F16, true, false>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<F16, false, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_rp16<BF16, true, false>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_rp16<BF16, false, false>(Q, K, V, O, BH, N, scale, stream);
+}
+
+}  // namespace fa

@@ -49,7 +49,7 @@ def _have_exp():
 
 
 def _algos_for(d):
-    algos = ((0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22) if d == 64
+    algos = ((0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24) if d == 64
              else ((0, 1, 2, 4, 13, 14, 15, 16, 21) if d == 128 else (0, 1)))
     return tuple(a for a in algos if a not in _EXPERIMENTAL or _have_exp())
 
@@ -300,7 +300,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     # 13, 14) sum the ROUNDED bf16 weights instead and meet the plain bar; the A/B variants do not.
     def tol(algo):
         return MAX_ABS * (2.0 if fmt == 1 and algo in (9, 11, 12) else 1.0)
-    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24) if a not in _EXPERIMENTAL or _have_exp()):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol(algo))
     # ragged N with the overflow in the partial last tile
@@ -309,7 +309,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     k2[0, n2 - 1] = q2[0, 200] * 40.0
     q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
     want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
-    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24) if a not in _EXPERIMENTAL or _have_exp()):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
         _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol(algo))
 
@@ -628,7 +628,7 @@ def test_auto_dispatch_boundaries(fa, oracle, torch_cuda, fmt):
     torch = torch_cuda
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     L = fa.lib()
-    big = 21 if fmt == 1 else 22
+    big = 21 if fmt == 1 else 24
     for (bh, n, want_algo) in [(cus - 1, 512, 6), (cus, 512, big), (2 * cus - 1, 256, 6), (2 * cus, 256, 5), (cus, 500, big), (cus // 2, 513, big), (4 * cus, 250, 5)]:
         sel = L.fa_selected_algo(bh, 1, n, 64, fmt)
         if want_algo is not None:
@@ -655,13 +655,13 @@ def test_bf16_overflow_window_below_inf(fa, oracle, torch_cuda):
     q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
     qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
     want = oracle.forward(q, k, v, accum=1, nthreads=8)
-    for algo in (a for a in (0, 5, 6, 13, 16, 21, 14, 17) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 13, 16, 21, 23, 14, 17) if a not in _EXPERIMENTAL or _have_exp()):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"bf16 window algo={algo}", max_abs=4 * MAX_ABS)   # |V| = 4 x the N(0,1) bar
 
 
 def test_folded_pass_gates(fa, oracle, torch_cuda):
-    """The fp16 fast pass of FA_ALGO_RP_FOLD (scale folded into a rounded Q, one reference maximum per wave) must hand a
+    """The fp16 fast pass of FA_ALGO_RP16_FOLD / FA_ALGO_RP_FOLD (scale folded into a rounded Q, one reference maximum per wave) must hand a
     workgroup to the exact pass whenever its assumptions fail, and agree with the exact kernel where they hold."""
     d, fmt = 64, 0
     cases = []
@@ -694,7 +694,7 @@ def test_folded_pass_gates(fa, oracle, torch_cuda):
         q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
         qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
         want = oracle.forward(q, k, v, accum=1, nthreads=8, **({} if scale is None else {"scale": scale}))
-        for algo in (22, 21, 0):
+        for algo in (24, 22, 21, 0):
             got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo, scale=scale)
             _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo}")
 
@@ -705,10 +705,11 @@ def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda):
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(7)
     q, k, v = (torch.randn(2, 16, 4096, 64, generator=g, device="cuda").half() for _ in range(3))
-    a = fa.fa_forward(q, k, v, algo=22)
-    b = fa.fa_forward(q, k, v, algo=21)
+    a = fa.fa_forward(q, k, v, algo=24)
+    b = fa.fa_forward(q, k, v, algo=23)
+    c = fa.fa_forward(q, k, v, algo=22)
     torch.cuda.synchronize()
-    assert float((a - b).abs().max()) <= 2e-3
+    assert float((a - b).abs().max()) <= 2e-3 and float((c - b).abs().max()) <= 2e-3
     _sampled_rows_check(fa, oracle, torch, q, k, v, a, 0, [(0, 0, 0, 32), (1, 15, 4064, 32), (1, 7, 2000, 16)], "folded pass")
 
 
