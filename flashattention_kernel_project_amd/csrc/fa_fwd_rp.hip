@@ -161,6 +161,9 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             // overflow (or NaN), or a row whose elements ALL fell below fp16's normal range (branch-free, per lane)
             if constexpr (fold) q_bad |= (int)!(amax <= 65504.0f) | ((int)(amax != 0.0f) & (int)(amax < 6.2e-5f));
         }
+        // pin the flag HERE: left to itself the compiler evaluates it after the tile loop and keeps all 64 fp32
+        // products alive (spilled) across it -- 33 MB of scratch written and read back per item
+        if constexpr (fold) asm volatile("" : "+v"(q_bad));
     };
 
     f32x16 o[X][G::kDBlocks];

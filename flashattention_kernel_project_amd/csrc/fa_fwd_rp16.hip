@@ -144,6 +144,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             }
             if constexpr (fold) q_bad |= (int)!(amax <= 65504.0f) | ((int)(amax != 0.0f) & (int)(amax < 6.2e-5f));
         }
+        // pin the flag HERE: left to itself the compiler evaluates it after the tile loop and keeps all 64 fp32
+        // products alive (spilled) across it -- 33 MB of scratch written and read back per item
+        if constexpr (fold) asm volatile("" : "+v"(q_bad));
     };
 
     f32x4 o[X][kDB];
@@ -334,13 +337,15 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of ring slot 3
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            kst = buf_load16(rk, (unsigned)pt * kTile + st_goff);
-            vst = buf_load16(rv, (unsigned)pt * kTile + st_goff);
-            if (pt == 0) lds_write16(smem, 3u * kSlotBytes + v_lds, zero4u);
-            lds_write16(smem, (unsigned)pt * kSlotBytes + k_lds, kst);
-            lds_write16(smem, (unsigned)pt * kSlotBytes + v_lds, vst);
+        {   // all four loads in flight together
+            kst = buf_load16(rk, st_goff);
+            vst = buf_load16(rv, st_goff);
+            const u32x4 k1 = buf_load16(rk, kTile + st_goff), v1 = buf_load16(rv, kTile + st_goff);
+            lds_write16(smem, 3u * kSlotBytes + v_lds, zero4u);
+            lds_write16(smem, k_lds, kst);
+            lds_write16(smem, v_lds, vst);
+            lds_write16(smem, kSlotBytes + k_lds, k1);
+            lds_write16(smem, kSlotBytes + v_lds, v1);
         }
         __syncthreads();
 #pragma unroll

@@ -47,7 +47,11 @@ def main():
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--out", default="f32")
+    ap.add_argument("--config", default=None, help="cfg3 | cfg4 | cfg4bf16 | cfg5 (sets B, H, N, d, dtype)")
     a = ap.parse_args()
+    if a.config:
+        a.B, a.H, a.N, a.d, a.dtype = {"cfg3": (4, 8, 1024, 64, "f16"), "cfg4": (8, 16, 4096, 64, "f16"),
+                                       "cfg4bf16": (8, 16, 4096, 64, "bf16"), "cfg5": (8, 16, 8192, 128, "f16")}[a.config]
     src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -78,6 +82,8 @@ def main():
         cyc = mf["GRBM_GUI_ACTIVE"] / 8.0                    # counter sums the 8 XCDs
         der["gpu_cycles_per_launch"] = cyc
         der["mfma_busy_frac_of_simd_time"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc   # 1024 SIMDs
+        if "SQ_VALU_MFMA_COEXEC_CYCLES" in mf:
+            der["mfma_coexec_over_mfma_busy"] = mf["SQ_VALU_MFMA_COEXEC_CYCLES"] / sq["SQ_VALU_MFMA_BUSY_CYCLES"]
         if kernel_ms:
             der["effective_clock_GHz_profiled"] = cyc / (kernel_ms * 1e-3) / 1e9
     if "SQ_WAVE_CYCLES" in sq:
@@ -94,16 +100,31 @@ def main():
         der["hbm_write_bytes_per_launch"] = wb
         der["hbm_bytes_per_launch"] = rd + wb
         der["hbm_bytes_over_algorithmic"] = (rd + wb) / alg_bytes
+        traffic_file = "hbm_traffic.json" if (a.B, a.H, a.N, a.d, a.dtype) == (8, 16, 4096, 64, "f16") else f"{a.tag}_hbm_traffic.json"
         json.dump({"config": {"B": a.B, "H": a.H, "N": a.N, "d": a.d, "dtype": a.dtype, "out": a.out},
+                   "kernel": (sq.get("_meta") or {}).get("Kernel_Name", ""),
                    "hbm_bytes_per_launch": rd + wb, "read_bytes_fetch_size_x2": rd, "write_bytes": wb,
                    "source": f"profiles/{a.tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"},
-                  open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+                  open(os.path.join(dst, traffic_file), "w"), indent=1)
     if "TCC_HIT_sum" in l2 and "TCC_MISS_sum" in l2:
         der["l2_hit_rate"] = l2["TCC_HIT_sum"] / (l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"])
     if kernel_ms:
         der["tflops_from_kernel_trace"] = flops / (kernel_ms * 1e-3) / 1e12
         der["frac_of_2500_TF_peak"] = der["tflops_from_kernel_trace"] / 2500.0
     summ["derived"] = der
+    # per-dispatch durations of the long kernel-trace run: the post-idle transient the driver's 5+20 window sits in
+    kl = one(os.path.join(src, "kt_long", "**", "*_kernel_trace.csv"))
+    if kl:
+        rows = [r for r in csv.DictReader(open(kl)) if "fa_fwd" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        with open(os.path.join(dst, f"{a.tag}_dispatch_times.csv"), "w") as f:
+            f.write("dispatch,start_us_since_first,duration_us\n")
+            t0 = int(rows[0]["Start_Timestamp"]) if rows else 0
+            for i, r in enumerate(rows):
+                f.write(f"{i},{(int(r['Start_Timestamp']) - t0) / 1e3:.1f},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f}\n")
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        if len(durs) >= 60:
+            summ["dispatch_us"] = {"first": durs[0], "mean_5_to_24": sum(durs[5:25]) / 20.0, "slowest": max(durs), "mean_last_50": sum(durs[-50:]) / 50.0}
     json.dump(summ, open(os.path.join(dst, f"{a.tag}_summary.json"), "w"), indent=1)
     print(json.dumps(der, indent=1))
 
