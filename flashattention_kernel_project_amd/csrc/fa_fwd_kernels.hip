@@ -534,7 +534,7 @@ const char* algo_kernel_name(int algo, int D)
         case 13: return "fa::fa_fwd_w64_kernel";
         case 16: return "fa::fa_fwd_w64x_kernel";
         case 21: case 22: return "fa::fa_fwd_rp_kernel";
-        case 23: case 24: return "fa::fa_fwd_rp16_kernel";
+        case 23: case 24: case 25: return "fa::fa_fwd_rp16_kernel";
         default: return "";
     }
 }
@@ -560,6 +560,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 23) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 24) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
 #ifdef FA_EXPERIMENTS
+    if (algo == 25) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 3, stream);   // 24 with LDS-DMA staging
     if (algo >= 17 && algo <= 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);

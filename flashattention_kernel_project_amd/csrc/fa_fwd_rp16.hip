@@ -56,7 +56,14 @@ constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
 #endif
 }  // namespace rp16
 
-template <typename T, bool kOutF32, bool kFold>
+// kDma: K/V tiles go HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, one 1-KB piece of the K image and one of the V image
+// per wave and tile, the images' permutations applied on the SOURCE address) instead of through registers
+// (buffer_load -> VGPR -> ds_write_b128).  This is the loader half of the reference's warp-specialised hand-off
+// (flashattn_streaming_16x16_mw_v5_warp_specialize.cu:121-185, _v11.cu:189-258) as far as CDNA4 affords it: the
+// register file is allocated per kernel, so a ninth (loader) wave would cut every wave to 170 registers, and a loader
+// among the eight idles an eighth of the matrix capacity (fixed roles: 43 vs 37.7 cycles per slot in the slot model),
+// so every wave issues the DMA for its own eighth of the tile and the hand-off is the counted wait + the tile barrier.
+template <typename T, bool kOutF32, bool kFold, bool kDma = false>
 __global__ __launch_bounds__(64 * rp16::kW, 2)
 void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -86,6 +93,17 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const unsigned st_goff = srow * kRowB + sch * 16u;
     const unsigned k_lds = G::k_off(srow, sch);
     const unsigned v_lds = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
+    // LDS-DMA: this wave's 1-KB piece of an image is bytes [1024 wave, +1024), lane l lands at +16 l; where that comes from
+    const unsigned dk_row = 8u * wave + (lane >> 3), dk_slot = lane & 7u;
+    const unsigned k_src = dk_row * kRowB + ((dk_slot ^ G::k_swz(dk_row)) << 4);
+    const unsigned dv_l = 1024u * wave + 16u * lane, dv_blk = dv_l >> 8;
+    const unsigned dv_row = (dv_blk / (unsigned)kDB) * 8u + ((dv_l & 255u) >> 5), dv_ch = (dv_blk % (unsigned)kDB) * 2u + ((dv_l >> 4) & 1u);
+    const unsigned v_src = dv_row * kRowB + dv_ch * 16u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma_tile = [&](__amdgpu_buffer_rsrc_t rks, __amdgpu_buffer_rsrc_t rvs, unsigned tile_off, unsigned slot_off) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rks, (lds_void*)(smem + slot_off + 1024u * wave), 16, tile_off + k_src, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rvs, (lds_void*)(smem + slot_off + kTile + 1024u * wave), 16, tile_off + v_src, 0, 0, 0);
+    };
     unsigned k_rd[kKS];
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) k_rd[ks] = c16 * kRowB + (((4u * ks + g) ^ G::k_swz(c16)) << 4);
@@ -249,7 +267,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         sfor<32>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT) {   // land tile j+2 (requested at the top of the iteration)
+            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT && !kDma) {   // land tile j+2 (requested at the top of the iteration)
                 lds_write16(smem, so_land + k_lds, kst);
                 lds_write16(smem, so_land + v_lds, vst);
             }
@@ -316,7 +334,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
                 for (int x = 0; x < X; ++x) s_nxt[x][kbl] = M::mfma(kf, qf[x][ks], ks == 0 ? zero4 : s_nxt[x][kbl]);
             }
-        if constexpr (h == 1) {
+        if constexpr (h == 1 && !kDma) {
             lds_write16(smem, so_land + k_lds, kst);
             lds_write16(smem, so_land + v_lds, vst);
         }
@@ -337,7 +355,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of ring slot 3
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
-        {   // all four loads in flight together
+        if constexpr (kDma) {
+            lds_write16(smem, 3u * kSlotBytes + v_lds, zero4u);
+            dma_tile(rk, rv, 0u, 0u);
+            dma_tile(rk, rv, kTile, kSlotBytes);
+        } else {   // all four loads in flight together
             kst = buf_load16(rk, st_goff);
             vst = buf_load16(rv, st_goff);
             const u32x4 k1 = buf_load16(rk, kTile + st_goff), v1 = buf_load16(rv, kTile + st_goff);
@@ -392,8 +414,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             const unsigned so_m1 = ((unsigned)(j + 3) & 3u) * kSlotBytes, so_0 = ((unsigned)j & 3u) * kSlotBytes;
             const unsigned so_p1 = ((unsigned)(j + 1) & 3u) * kSlotBytes, so_p2 = ((unsigned)(j + 2) & 3u) * kSlotBytes;
             // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
-            kst = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff);
-            vst = buf_load16(rv, (unsigned)(j + 2) * kTile + st_goff);
+            if constexpr (kDma) {
+                dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_p2);   // the barrier below waits for it (vmcnt) and publishes it
+            } else {
+                kst = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff);
+                vst = buf_load16(rv, (unsigned)(j + 2) * kTile + st_goff);
+            }
             if constexpr (kTrack) {
                 step_tracked(c0{}, j, sA, sB, pkB, pkA, so_0, so_m1, so_p2);
                 step_tracked(c1{}, j, sB, sA, pkA, pkB, so_p1, so_0, so_p2);
@@ -476,7 +502,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, bool kOutF32, bool kFold>
+template <typename T, bool kOutF32, bool kFold, bool kDma = false>
 static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
@@ -488,7 +514,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const long long cap = device_cus();
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    auto kern = fa_fwd_rp16_kernel<T, kOutF32, kFold>;
+    auto kern = fa_fwd_rp16_kernel<T, kOutF32, kFold, kDma>;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
     if (attr != hipSuccess) return attr;
     FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
@@ -497,14 +523,30 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     return hipGetLastError();
 }
 
-// fold: 1 = folded fast pass (fp16), 0 = exact passes only
+// fold: 1 = folded fast pass (fp16), 0 = exact passes only; +2 = K/V staging by LDS-DMA
 hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
                          hipStream_t stream)
 {
     if (D != 64) return hipErrorInvalidValue;
     if ((unsigned long long)(N + 64 * rp16::kW + 3 * kBlockN) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    const bool dma = (fold & 2) != 0;
+    fold &= 1;
     if (!(scale == scale) || scale * kLog2e == 0.0f) fold = 0;
+#ifndef FA_EXPERIMENTS
+    if (dma) return hipErrorInvalidValue;   // the LDS-DMA variant lost the A/B (0.552 vs 0.508 ms): experimental build only
+#else
+    if (dma) {
+        if (in_dtype == 0 && fold)
+            return out_dtype == 0 ? launch_rp16<F16, true, true, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<F16, false, true, true>(Q, K, V, O, BH, N, scale, stream);
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_rp16<F16, true, false, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<F16, false, false, true>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_rp16<BF16, true, false, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<BF16, false, false, true>(Q, K, V, O, BH, N, scale, stream);
+    }
+#endif
     if (in_dtype == 0 && fold)
         return out_dtype == 0 ? launch_rp16<F16, true, true>(Q, K, V, O, BH, N, scale, stream)
                               : launch_rp16<F16, false, true>(Q, K, V, O, BH, N, scale, stream);

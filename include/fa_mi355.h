@@ -52,6 +52,7 @@ extern "C" {
 #define FA_ALGO_IL2X16         12 /* 8 waves x two 16-row blocks sharing K/V fragments, 16x16x32, D = 64 */
 #define FA_ALGO_W64P           14 /* W64 with a half-tile rolling pipeline, packed fp32 (round 1's form of RP), D in {64,128} */
 #define FA_ALGO_W64M           15 /* W64 with QK^T one tile ahead, merged with PV into one matrix phase */
+#define FA_ALGO_RP16_DMA       25 /* RP16_FOLD with K/V staged by LDS-DMA (buffer_load ... lds) instead of through registers */
 #define FA_ALGO_SK             17 /* skewed halves: waves 4-7 half an iteration behind waves 0-3, folded fast pass; 18 exact, 19/20 lock-step */
 /* 7, 8, 10: occupancy variants of TILED (fp16, d=64). */
 
