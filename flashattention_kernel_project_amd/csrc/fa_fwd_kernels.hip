@@ -508,7 +508,8 @@ hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
 //     interleaved A/B: fp16 0.500 ms (24) / 0.524 (22, the same on 32x32x16) / 0.526 (23) / 0.541 (fa_fwd_w64x);
 //     bf16 0.522 (21) / 0.530 (23) / 0.532 (fa_fwd_w64);
 //   d = 64, smaller grids: the interleaved kernel with 256-row workgroups, or 128-row ones (two per CU);
-//   d = 128: fa_fwd_w64x for fp16 (3.86 vs 4.04 ms at N 8192), fa_fwd_w64 for bf16 (3.78 vs 3.92 ms);
+//   d = 128: the same pipeline with two 16-row blocks per wave (256-row workgroups): fp16 24 (B8 H16 N8192: 3.74 ms against
+//     3.94 for fa_fwd_w64x, 4.09 for fa_fwd_w64), bf16 23 (3.81 against 3.84 for fa_fwd_w64);
 //   anything else: the generic single-fragment kernel.
 // The CU count is read from the current device per call.
 int auto_algo(int BH, int N, int D, int in_dtype)
@@ -520,7 +521,7 @@ int auto_algo(int BH, int N, int D, int in_dtype)
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return nwg256 >= 2 * cus ? 5 : 6;
     }
-    if (D == 128) return in_dtype == 0 ? 16 : 13;
+    if (D == 128) return in_dtype == 0 ? 24 : 23;
     return 1;
 }
 

@@ -43,7 +43,7 @@ template <> struct Mx<BF16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
-constexpr int kW = 8, X = 4, D = 64;
+constexpr int kW = 8;
 #ifndef FA_RP16_AHEAD
 #define FA_RP16_AHEAD 2
 #endif
@@ -63,7 +63,9 @@ constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
 // register file is allocated per kernel, so a ninth (loader) wave would cut every wave to 170 registers, and a loader
 // among the eight idles an eighth of the matrix capacity (fixed roles: 43 vs 37.7 cycles per slot in the slot model),
 // so every wave issues the DMA for its own eighth of the tile and the hand-off is the counted wait + the tile barrier.
-template <typename T, bool kOutF32, bool kFold, bool kDma = false>
+// D = head dim (64 or 128); X = 16-row query blocks per wave (4 at D = 64: 64 rows, 512-row workgroups; 2 at D = 128: 32 rows,
+// 256-row workgroups).  A step always is 32 matrix instructions: 2*D/32 K fragments and D/16 V^T fragments, each feeding X blocks.
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false>
 __global__ __launch_bounds__(64 * rp16::kW, 2)
 void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -73,8 +75,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     using M = Mx<T>;
     using G = TileGeom<D>;
     static_assert(!kFold || T::id == 0, "the folded pass rounds Q*scale to fp16");
+    static_assert(!kDma || D == 64, "the DMA piece maps are written for 128-byte rows");
     constexpr int kRows = 16 * X * kW;
-    constexpr int kKS = D / 32, kDB = D / 16;   // k-steps of QK^T (2), 16-row blocks of O^T (4)
+    constexpr int kKS = D / 32, kDB = D / 16;   // k-steps of QK^T, 16-row blocks of O^T
+    constexpr int kNF = 2 * kKS + kDB;          // fragments per step (K and V^T alternate: 2 kKS == kDB)
+    static_assert(2 * kKS == kDB && kNF * X == 32 && kNF % kRing == 0, "a step is 32 matrix instructions");
+    constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);   // 16-B chunks of K (and of V) per thread and tile
     constexpr unsigned kRowB = D * 2;
     constexpr unsigned kTile = kBlockN * D * 2;
     constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
@@ -89,10 +95,15 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const int ntiles = (N + kBlockN - 1) / kBlockN;
     const bool partial = (N % kBlockN) != 0;
 
-    const unsigned srow = tid / G::kChunks, sch = tid % G::kChunks;
-    const unsigned st_goff = srow * kRowB + sch * 16u;
-    const unsigned k_lds = G::k_off(srow, sch);
-    const unsigned v_lds = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
+    unsigned st_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
+#pragma unroll
+    for (int p = 0; p < kLoads; ++p) {
+        const unsigned idx = tid + p * 64u * kW;
+        const unsigned srow = idx / G::kChunks, sch = idx % G::kChunks;
+        st_goff[p] = srow * kRowB + sch * 16u;
+        k_lds[p] = G::k_off(srow, sch);
+        v_lds[p] = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
+    }
     // LDS-DMA: this wave's 1-KB piece of an image is bytes [1024 wave, +1024), lane l lands at +16 l; where that comes from
     const unsigned dk_row = 8u * wave + (lane >> 3), dk_slot = lane & 7u;
     const unsigned k_src = dk_row * kRowB + ((dk_slot ^ G::k_swz(dk_row)) << 4);
@@ -169,7 +180,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 
     f32x4 o[X][kDB];
     float m_ref[X] = {}, l_part[X] = {};
-    u32x4 kst, vst;
+    u32x4 kst[kLoads], vst[kLoads];
     u32x4 frag[kRing];
     f32x4 minit;   // folded pass: every score chain starts at -(wave reference maximum)
 
@@ -187,11 +198,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
         return vf;
     };
-    // fragment f (0..7) of a step: even f -> K fragment (kbl = f/4, ks = (f/2)&1) of the QK^T unit, odd f -> V^T fragment
-    // db = f/2 of the PV unit
+    // fragment f (0..kNF-1) of a step: even f -> K fragment (kbl = (f/2) / kKS, ks = (f/2) % kKS) of the QK^T unit,
+    // odd f -> V^T fragment db = f/2 of the PV unit
     auto read_frag = [&](auto fc, unsigned so_q, int h_q, unsigned so_v, int h_v) {
         constexpr int f = decltype(fc)::value;
-        if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, h_q, f >> 2, (f >> 1) & 1);
+        if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, h_q, (f >> 1) / kKS, (f >> 1) % kKS);
         else frag[f % kRing] = read_vf(so_v, h_v, f >> 1);
     };
     auto mask_unit = [&](int tile, int h, f32x4 (&s)[X][2]) {   // keys >= N -> -inf (p = 0)
@@ -251,7 +262,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         auto issue_mfma = [&](auto ic) {
             constexpr int i = decltype(ic)::value, f = i / X, x = i % X;
             if constexpr ((f & 1) == 0) {
-                constexpr int kbl = f >> 2, ks = (f >> 1) & 1;
+                constexpr int kbl = (f >> 1) / kKS, ks = (f >> 1) % kKS;
                 s_nxt[x][kbl] = M::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
             } else {
                 constexpr int db = f >> 1;
@@ -268,16 +279,20 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT && !kDma) {   // land tile j+2 (requested at the top of the iteration)
-                lds_write16(smem, so_land + k_lds, kst);
-                lds_write16(smem, so_land + v_lds, vst);
+#pragma unroll
+                for (int p = 0; p < kLoads; ++p) {
+                    lds_write16(smem, so_land + k_lds[p], kst[p]);
+                    lds_write16(smem, so_land + v_lds[p], vst[p]);
+                }
             }
             issue_mfma(ic);
             if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
                 constexpr int f = i / X + kAhead;
-                if constexpr (f < 8) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
-                else read_frag(std::integral_constant<int, f - 8>{}, so_nq, h, so_nv, h);
+                if constexpr (f < kNF) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
+                else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
             }
-            if constexpr (i % 2 == 1) valu_step(std::integral_constant<int, i / 2>{});   // one pair-step per two matrix slots
+            constexpr int kPer = 32 / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
+            if constexpr (i % kPer == kPer - 1) valu_step(std::integral_constant<int, i / kPer>{});
         });
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -335,8 +350,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 for (int x = 0; x < X; ++x) s_nxt[x][kbl] = M::mfma(kf, qf[x][ks], ks == 0 ? zero4 : s_nxt[x][kbl]);
             }
         if constexpr (h == 1 && !kDma) {
-            lds_write16(smem, so_land + k_lds, kst);
-            lds_write16(smem, so_land + v_lds, vst);
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                lds_write16(smem, so_land + k_lds[p], kst[p]);
+                lds_write16(smem, so_land + v_lds[p], vst[p]);
+            }
         }
     };
 
@@ -356,18 +374,27 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
         if constexpr (kDma) {
-            lds_write16(smem, 3u * kSlotBytes + v_lds, zero4u);
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
             dma_tile(rk, rv, 0u, 0u);
             dma_tile(rk, rv, kTile, kSlotBytes);
-        } else {   // all four loads in flight together
-            kst = buf_load16(rk, st_goff);
-            vst = buf_load16(rv, st_goff);
-            const u32x4 k1 = buf_load16(rk, kTile + st_goff), v1 = buf_load16(rv, kTile + st_goff);
-            lds_write16(smem, 3u * kSlotBytes + v_lds, zero4u);
-            lds_write16(smem, k_lds, kst);
-            lds_write16(smem, v_lds, vst);
-            lds_write16(smem, kSlotBytes + k_lds, k1);
-            lds_write16(smem, kSlotBytes + v_lds, v1);
+        } else {   // all loads of both tiles in flight together
+            u32x4 k1[kLoads], v1[kLoads];
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                kst[p] = buf_load16(rk, st_goff[p]);
+                vst[p] = buf_load16(rv, st_goff[p]);
+                k1[p] = buf_load16(rk, kTile + st_goff[p]);
+                v1[p] = buf_load16(rv, kTile + st_goff[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < kLoads; ++p) {
+                lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
+                lds_write16(smem, k_lds[p], kst[p]);
+                lds_write16(smem, v_lds[p], vst[p]);
+                lds_write16(smem, kSlotBytes + k_lds[p], k1[p]);
+                lds_write16(smem, kSlotBytes + v_lds[p], v1[p]);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -417,8 +444,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             if constexpr (kDma) {
                 dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_p2);   // the barrier below waits for it (vmcnt) and publishes it
             } else {
-                kst = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff);
-                vst = buf_load16(rv, (unsigned)(j + 2) * kTile + st_goff);
+#pragma unroll
+                for (int p = 0; p < kLoads; ++p) {
+                    kst[p] = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff[p]);
+                    vst[p] = buf_load16(rv, (unsigned)(j + 2) * kTile + st_goff[p]);
+                }
             }
             if constexpr (kTrack) {
                 step_tracked(c0{}, j, sA, sB, pkB, pkA, so_0, so_m1, so_p2);
@@ -502,7 +532,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, bool kOutF32, bool kFold, bool kDma = false>
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false>
 static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
@@ -514,7 +544,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const long long cap = device_cus();
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    auto kern = fa_fwd_rp16_kernel<T, kOutF32, kFold, kDma>;
+    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma>;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
     if (attr != hipSuccess) return attr;
     FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
@@ -528,33 +558,44 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
                          hipStream_t stream)
 {
-    if (D != 64) return hipErrorInvalidValue;
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
     if ((unsigned long long)(N + 64 * rp16::kW + 3 * kBlockN) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     const bool dma = (fold & 2) != 0;
     fold &= 1;
     if (!(scale == scale) || scale * kLog2e == 0.0f) fold = 0;
+    if (D == 128) {
+        if (dma) return hipErrorInvalidValue;
+        if (in_dtype == 0 && fold)
+            return out_dtype == 0 ? launch_rp16<F16, 128, 2, true, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<F16, 128, 2, false, true>(Q, K, V, O, BH, N, scale, stream);
+        if (in_dtype == 0)
+            return out_dtype == 0 ? launch_rp16<F16, 128, 2, true, false>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<F16, 128, 2, false, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_rp16<BF16, 128, 2, true, false>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<BF16, 128, 2, false, false>(Q, K, V, O, BH, N, scale, stream);
+    }
 #ifndef FA_EXPERIMENTS
     if (dma) return hipErrorInvalidValue;   // the LDS-DMA variant lost the A/B (0.552 vs 0.508 ms): experimental build only
 #else
     if (dma) {
         if (in_dtype == 0 && fold)
-            return out_dtype == 0 ? launch_rp16<F16, true, true, true>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_rp16<F16, false, true, true>(Q, K, V, O, BH, N, scale, stream);
+            return out_dtype == 0 ? launch_rp16<F16, 64, 4, true, true, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<F16, 64, 4, false, true, true>(Q, K, V, O, BH, N, scale, stream);
         if (in_dtype == 0)
-            return out_dtype == 0 ? launch_rp16<F16, true, false, true>(Q, K, V, O, BH, N, scale, stream)
-                                  : launch_rp16<F16, false, false, true>(Q, K, V, O, BH, N, scale, stream);
-        return out_dtype == 0 ? launch_rp16<BF16, true, false, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_rp16<BF16, false, false, true>(Q, K, V, O, BH, N, scale, stream);
+            return out_dtype == 0 ? launch_rp16<F16, 64, 4, true, false, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<F16, 64, 4, false, false, true>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_rp16<BF16, 64, 4, true, false, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<BF16, 64, 4, false, false, true>(Q, K, V, O, BH, N, scale, stream);
     }
 #endif
     if (in_dtype == 0 && fold)
-        return out_dtype == 0 ? launch_rp16<F16, true, true>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_rp16<F16, false, true>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_rp16<F16, 64, 4, true, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<F16, 64, 4, false, true>(Q, K, V, O, BH, N, scale, stream);
     if (in_dtype == 0)
-        return out_dtype == 0 ? launch_rp16<F16, true, false>(Q, K, V, O, BH, N, scale, stream)
-                              : launch_rp16<F16, false, false>(Q, K, V, O, BH, N, scale, stream);
-    return out_dtype == 0 ? launch_rp16<BF16, true, false>(Q, K, V, O, BH, N, scale, stream)
-                          : launch_rp16<BF16, false, false>(Q, K, V, O, BH, N, scale, stream);
+        return out_dtype == 0 ? launch_rp16<F16, 64, 4, true, false>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<F16, 64, 4, false, false>(Q, K, V, O, BH, N, scale, stream);
+    return out_dtype == 0 ? launch_rp16<BF16, 64, 4, true, false>(Q, K, V, O, BH, N, scale, stream)
+                          : launch_rp16<BF16, 64, 4, false, false>(Q, K, V, O, BH, N, scale, stream);
 }
 
 }  // namespace fa

@@ -50,7 +50,7 @@ def _have_exp():
 
 def _algos_for(d):
     algos = ((0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25) if d == 64
-             else ((0, 1, 2, 4, 13, 14, 15, 16, 21) if d == 128 else (0, 1)))
+             else ((0, 1, 2, 4, 13, 14, 15, 16, 21, 23, 24) if d == 128 else (0, 1)))
     return tuple(a for a in algos if a not in _EXPERIMENTAL or _have_exp())
 
 
