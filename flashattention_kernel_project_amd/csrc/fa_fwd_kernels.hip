@@ -503,13 +503,13 @@ hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
                            hipStream_t stream);
 
 // AUTO: the explicit algo id a shape resolves to (one rule for the dispatcher and for fa_selected_kernel()).
-//   d = 64, N > 256 and at least one 512-row workgroup per CU: the rolling half-tile pipeline -- fp16 on 16x16x32 with the
-//     folded fast pass (fa_fwd_rp16.hip, 24), bf16 on 32x32x16 with the exact pass (fa_fwd_rp.hip, 21).  Round 2, one device,
-//     interleaved A/B: fp16 0.500 ms (24) / 0.524 (22, the same on 32x32x16) / 0.526 (23) / 0.541 (fa_fwd_w64x);
-//     bf16 0.522 (21) / 0.530 (23) / 0.532 (fa_fwd_w64);
-//   d = 64, smaller grids: the interleaved kernel with 256-row workgroups, or 128-row ones (two per CU);
-//   d = 128: the same pipeline with two 16-row blocks per wave (256-row workgroups): fp16 24 (B8 H16 N8192: 3.74 ms against
-//     3.94 for fa_fwd_w64x, 4.09 for fa_fwd_w64), bf16 23 (3.81 against 3.84 for fa_fwd_w64);
+//   d = 64, N > 256 and at least one 512-row workgroup per CU: the rolling half-tile pipeline on 16x16x32 with the folded
+//     fast pass (fa_fwd_rp16.hip, 24), fp16 and bf16.  Round 2, one device, interleaved A/B, B8 H16 N4096, ms per launch:
+//     fp16 0.489 (24) / 0.524 (22, the same on 32x32x16) / 0.526 (23, exact) / 0.541 (fa_fwd_w64x);
+//     bf16 0.487 (24) / 0.502 (23) / 0.528 (21, fa_fwd_rp) / 0.533 (fa_fwd_w64);
+//   d = 64, smaller grids or N <= 256: the interleaved kernel with 256-row workgroups, or 128-row ones (two per CU);
+//   d = 128: the same pipeline with two 16-row blocks per wave (256-row workgroups), B8 H16 N8192: fp16 3.74 ms against 3.94
+//     for fa_fwd_w64x, bf16 3.63 against 3.84 for fa_fwd_w64;
 //   anything else: the generic single-fragment kernel.
 // The CU count is read from the current device per call.
 int auto_algo(int BH, int N, int D, int in_dtype)
@@ -517,11 +517,11 @@ int auto_algo(int BH, int N, int D, int in_dtype)
     if (D == 64) {
         const long long cus = device_cus();
         const long long nwg512 = (long long)BH * ((N + 511) / 512);
-        if (N > 256 && nwg512 >= cus) return in_dtype == 0 ? 24 : 21;   // N <= 256 would leave half of every 512-row workgroup idle
+        if (N > 256 && nwg512 >= cus) return 24;   // N <= 256 would leave half of every 512-row workgroup idle
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return nwg256 >= 2 * cus ? 5 : 6;
     }
-    if (D == 128) return in_dtype == 0 ? 24 : 23;
+    if (D == 128) return 24;
     return 1;
 }
 

@@ -51,6 +51,9 @@ constexpr int kAhead = FA_RP16_AHEAD;   // fragments read ahead of their MFMAs (
 constexpr int kRing = 4;           // fragment registers (8 fragments per step)
 constexpr float kHeadroom = 4.0f;
 constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
+#ifndef FA_RP16_RUNSUM
+#define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
+#endif
 #ifndef FA_RP16_STAGE_SLOT
 #define FA_RP16_STAGE_SLOT 16      // matrix slot of the second step in front of which tile j+2 is written to LDS
 #endif
@@ -74,7 +77,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     using namespace rp16;
     using M = Mx<T>;
     using G = TileGeom<D>;
-    static_assert(!kFold || T::id == 0, "the folded pass rounds Q*scale to fp16");
+    // The folded pass multiplies Q'.K on the fp16 matrix instruction whatever the input type: Q' = fp16(Q * scale * log2 e)
+    // (bf16's 8 bits would move a logit by |logit| * 2^-8), and bf16 K is converted to fp16 while it is staged -- exact for
+    // every bf16 value up to 65504 in magnitude (larger ones raise the gate; smaller ones lose at most 2^-25 absolutely).
+    // P and V stay in the input type for O^T += V^T.P^T.
+    constexpr bool kCvtK = kFold && T::id == 1;
+    static_assert(!(kCvtK && kDma), "the DMA path cannot convert K on the way");
     static_assert(!kDma || D == 64, "the DMA piece maps are written for 128-byte rows");
     constexpr int kRows = 16 * X * kW;
     constexpr int kKS = D / 32, kDB = D / 16;   // k-steps of QK^T, 16-row blocks of O^T
@@ -164,7 +172,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     if constexpr (fold) {
                         const float lo = T::lo(raw[w]) * scale_log2e, hi = T::hi(raw[w]) * scale_log2e;
                         amax = max3(amax, fabsf(lo), fabsf(hi));
-                        raw[w] = T::pack2(lo, hi);
+                        raw[w] = F16::pack2(lo, hi);
                     } else {
                         raw[w] ^= q_flip;
                     }
@@ -178,8 +186,22 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         if constexpr (fold) asm volatile("" : "+v"(q_bad));
     };
 
+    // bf16 K chunk -> fp16 (folded pass of bf16 inputs); k_amax collects the largest magnitude this thread converted
+    float k_amax = 0.0f;
+    auto k_to_f16 = [&](u32x4 kb) -> u32x4 {
+        u32x4 r;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float lo = BF16::lo(kb[w]), hi = BF16::hi(kb[w]);
+            k_amax = max3(k_amax, fabsf(lo), fabsf(hi));
+            r[w] = F16::pack2(lo, hi);
+        }
+        return r;
+    };
+
     f32x4 o[X][kDB];
     float m_ref[X] = {}, l_part[X] = {};
+    float ls[X][2];   // optimistic passes: two running row-sum chains per block, folded into l_part once per item
     u32x4 kst[kLoads], vst[kLoads];
     u32x4 frag[kRing];
     f32x4 minit;   // folded pass: every score chain starts at -(wave reference maximum)
@@ -229,9 +251,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         if constexpr (decltype(masked_c)::value) mask_unit(tile, h, s_cur);
 
         constexpr int kPairs = 4 * X;   // vector pair-steps: pair j = (block j/4, key block (j/2)&1, registers 2(j&1), 2(j&1)+1)
-        float ls[X][2];
+        if constexpr (!FA_RP16_RUNSUM) {
 #pragma unroll
-        for (int x = 0; x < X; ++x) ls[x][0] = ls[x][1] = 0.0f;
+            for (int x = 0; x < X; ++x) ls[x][0] = ls[x][1] = 0.0f;
+        }
         auto fma_pair = [&](auto jc) {
             constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
             s_cur[x][kbl][e] = __builtin_fmaf(s_cur[x][kbl][e], c, -m_ref[x]);
@@ -263,7 +286,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             constexpr int i = decltype(ic)::value, f = i / X, x = i % X;
             if constexpr ((f & 1) == 0) {
                 constexpr int kbl = (f >> 1) / kKS, ks = (f >> 1) % kKS;
-                s_nxt[x][kbl] = M::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
+                using MQ = std::conditional_t<kCvtK && kFast, Mx<F16>, M>;
+                s_nxt[x][kbl] = MQ::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
             } else {
                 constexpr int db = f >> 1;
                 o[x][db] = M::mfma(frag[f % kRing], pk_prev[x], o[x][db]);
@@ -281,7 +305,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT && !kDma) {   // land tile j+2 (requested at the top of the iteration)
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
-                    lds_write16(smem, so_land + k_lds[p], kst[p]);
+                    lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
                     lds_write16(smem, so_land + v_lds[p], vst[p]);
                 }
             }
@@ -295,8 +319,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             if constexpr (i % kPer == kPer - 1) valu_step(std::integral_constant<int, i / kPer>{});
         });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!FA_RP16_RUNSUM) {
 #pragma unroll
-        for (int x = 0; x < X; ++x) l_part[x] += ls[x][0] + ls[x][1];
+            for (int x = 0; x < X; ++x) l_part[x] += ls[x][0] + ls[x][1];
+        }
     };
 
     // One step of the tracked (fallback) pass: same data flow in plain program order with the lazy running max.
@@ -370,6 +396,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
             for (int db = 0; db < kDB; ++db) o[x][db] = zero4;
             l_part[x] = 0.0f;
+            ls[x][0] = ls[x][1] = 0.0f;
             pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of ring slot 3
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
@@ -390,9 +417,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
                 lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
-                lds_write16(smem, k_lds[p], kst[p]);
+                lds_write16(smem, k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
                 lds_write16(smem, v_lds[p], vst[p]);
-                lds_write16(smem, kSlotBytes + k_lds[p], k1[p]);
+                lds_write16(smem, kSlotBytes + k_lds[p], (kCvtK && kFast) ? k_to_f16(k1[p]) : k1[p]);
                 lds_write16(smem, kSlotBytes + v_lds[p], v1[p]);
             }
         }
@@ -402,8 +429,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks) {
                 const u32x4 kf = read_kf(0u, 0, kbl, ks);
+                using MQ = std::conditional_t<kCvtK && kFast, Mx<F16>, M>;
 #pragma unroll
-                for (int x = 0; x < X; ++x) sA[x][kbl] = M::mfma(kf, qf[x][ks], ks == 0 ? zero4 : sA[x][kbl]);
+                for (int x = 0; x < X; ++x) sA[x][kbl] = MQ::mfma(kf, qf[x][ks], ks == 0 ? zero4 : sA[x][kbl]);
             }
         {
             // reference max from the first 32 keys (masked copy when N < 32; the step masks again)
@@ -468,6 +496,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             for (int j = 0; j < nfull; ++j) tile_iter(j, no);
             if (partial) tile_iter(ntiles - 1, yes);
         }
+        if constexpr (!kTrack && FA_RP16_RUNSUM) {
+#pragma unroll
+            for (int x = 0; x < X; ++x) l_part[x] = ls[x][0] + ls[x][1];
+        }
         // ---- epilogue: O^T += V(last tile, half 1)^T.P^T ----
         {
             const unsigned so = ((unsigned)(ntiles - 1) & 3u) * kSlotBytes;
@@ -484,15 +516,18 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
     bool bad = false;
     if constexpr (kFold) {
+        k_amax = 0.0f;
         load_q(yes);
         run(std::integral_constant<int, 0>{});
-        const float lo = (float)N * 0x1p-14f;
+        // fp16 weights: subnormal ones must add up to < 2^-11 of the row; bf16 weights only must not vanish in fp32 (a row
+        // more than ~100 log2 units below its wave's reference: p = 0, l = 0)
+        const float lo = T::id == 0 ? (float)N * 0x1p-14f : 0x1p-100f;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             l_row[x] = across_sum(l_part[x]);
             bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo) || !(fabsf(m_ref[x]) <= kFoldMax);
         }
-        bad = bad || q_bad != 0;
+        bad = bad || q_bad != 0 || !(k_amax <= 65504.0f);
     } else {
         load_q(no);
         run(std::integral_constant<int, 1>{});
@@ -571,6 +606,9 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
         if (in_dtype == 0)
             return out_dtype == 0 ? launch_rp16<F16, 128, 2, true, false>(Q, K, V, O, BH, N, scale, stream)
                                   : launch_rp16<F16, 128, 2, false, false>(Q, K, V, O, BH, N, scale, stream);
+        if (fold)
+            return out_dtype == 0 ? launch_rp16<BF16, 128, 2, true, true>(Q, K, V, O, BH, N, scale, stream)
+                                  : launch_rp16<BF16, 128, 2, false, true>(Q, K, V, O, BH, N, scale, stream);
         return out_dtype == 0 ? launch_rp16<BF16, 128, 2, true, false>(Q, K, V, O, BH, N, scale, stream)
                               : launch_rp16<BF16, 128, 2, false, false>(Q, K, V, O, BH, N, scale, stream);
     }
@@ -594,6 +632,9 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
     if (in_dtype == 0)
         return out_dtype == 0 ? launch_rp16<F16, 64, 4, true, false>(Q, K, V, O, BH, N, scale, stream)
                               : launch_rp16<F16, 64, 4, false, false>(Q, K, V, O, BH, N, scale, stream);
+    if (fold)
+        return out_dtype == 0 ? launch_rp16<BF16, 64, 4, true, true>(Q, K, V, O, BH, N, scale, stream)
+                              : launch_rp16<BF16, 64, 4, false, true>(Q, K, V, O, BH, N, scale, stream);
     return out_dtype == 0 ? launch_rp16<BF16, 64, 4, true, false>(Q, K, V, O, BH, N, scale, stream)
                           : launch_rp16<BF16, 64, 4, false, false>(Q, K, V, O, BH, N, scale, stream);
 }

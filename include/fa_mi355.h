@@ -30,8 +30,8 @@ extern "C" {
 #define FA_OUT_SAME   1   /* output in the input's 16-bit type */
 
 /* Kernel selection for fa_forward_ex().  Ids present in the product library: */
-#define FA_ALGO_AUTO            0 /* d=64: RP16_FOLD for fp16 / RP for bf16 (INTERLEAVED / _2WG when N <= 256 or the grid is smaller than one
-                                     512-row workgroup per CU); d=128: RP16_FOLD for fp16 / RP16 for bf16; else GENERIC -- fa_selected_algo() */
+#define FA_ALGO_AUTO            0 /* d=64: RP16_FOLD (INTERLEAVED / _2WG when N <= 256 or the grid is smaller than one
+                                     512-row workgroup per CU); d=128: RP16_FOLD; else GENERIC -- fa_selected_algo() */
 #define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
 #define FA_ALGO_INTERLEAVED     5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
@@ -42,7 +42,7 @@ extern "C" {
 #define FA_ALGO_RP_FOLD        22 /* RP with the folded fast pass (scale folded into a rounded Q, wave reference max as accumulator
                                      start; exact tracked pass as fallback), fp16 at D = 64; other inputs run RP */
 #define FA_ALGO_RP16           23 /* RP on v_mfma_f32_16x16x32 (four 16-row blocks per wave at D = 64, two at D = 128), exact passes */
-#define FA_ALGO_RP16_FOLD      24 /* RP16 with the folded fast pass (fp16); other inputs run RP16 */
+#define FA_ALGO_RP16_FOLD      24 /* RP16 with the folded fast pass (fp16; bf16 with K converted to fp16 while it is staged) */
 /* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
  * A/B kernels that AUTO never selects. */
 #define FA_ALGO_PIPE            3 /* TILED with QK^T of tile t+1 under the softmax of tile t, D = 64 */

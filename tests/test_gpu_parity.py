@@ -628,7 +628,7 @@ def test_auto_dispatch_boundaries(fa, oracle, torch_cuda, fmt):
     torch = torch_cuda
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     L = fa.lib()
-    big = 21 if fmt == 1 else 24
+    big = 24
     for (bh, n, want_algo) in [(cus - 1, 512, 6), (cus, 512, big), (2 * cus - 1, 256, 6), (2 * cus, 256, 5), (cus, 500, big), (cus // 2, 513, big), (4 * cus, 250, 5)]:
         sel = L.fa_selected_algo(bh, 1, n, 64, fmt)
         if want_algo is not None:
@@ -660,10 +660,11 @@ def test_bf16_overflow_window_below_inf(fa, oracle, torch_cuda):
         _check(oracle, got, want, fmt, f"bf16 window algo={algo}", max_abs=4 * MAX_ABS)   # |V| = 4 x the N(0,1) bar
 
 
-def test_folded_pass_gates(fa, oracle, torch_cuda):
-    """The fp16 fast pass of FA_ALGO_RP16_FOLD / FA_ALGO_RP_FOLD (scale folded into a rounded Q, one reference maximum per wave) must hand a
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_folded_pass_gates(fa, oracle, torch_cuda, fmt):
+    """The fast pass of FA_ALGO_RP16_FOLD / FA_ALGO_RP_FOLD (scale folded into a rounded Q, one reference maximum per wave) must hand a
     workgroup to the exact pass whenever its assumptions fail, and agree with the exact kernel where they hold."""
-    d, fmt = 64, 0
+    d = 64
     cases = []
     # (a) rows of one wave with very different maxima: the wave reference sits far above some rows' scores
     (q, k, v), _ = oracle.make_qkv(2, 576, d, fmt, seed=61)
@@ -690,27 +691,38 @@ def test_folded_pass_gates(fa, oracle, torch_cuda):
     k[0, 64:] = -np.abs(k[0, 64:]) * 3.0
     q[0] = np.abs(q[0])
     cases.append(("late keys all far below", q, k, v, None))
+    # (g) one row hundreds of log2 units below its wave's reference (its weights vanish in fp32), single key
+    (q, k, v), _ = oracle.make_qkv(1, 1, d, fmt, seed=68)
+    q[0, 0] = -np.abs(k[0, 0]) * 6.0
+    cases.append(("row far below the wave reference", q, k * 6.0, v, 1.0))
+    # (h) K beyond fp16's range (bf16 inputs: the converted K overflows; fp16 inputs cannot hold it)
+    if fmt == 1:
+        (q, k, v), _ = oracle.make_qkv(1, 192, d, fmt, seed=69)
+        k[0, 100] *= 1e5
+        cases.append(("K beyond fp16 range", q * 1e-4, k, v, None))
     for (name, q, k, v, scale) in cases:
         q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
         qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
         want = oracle.forward(q, k, v, accum=1, nthreads=8, **({} if scale is None else {"scale": scale}))
         for algo in (24, 22, 21, 0):
             got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo, scale=scale)
-            _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo}")
+            _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo} fmt={fmt}", max_abs=MAX_ABS * (1.0 if fmt == 0 else 2.5))
 
 
-def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda):
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda, fmt):
     """N(0,1) inputs at the bench shape: the folded pass is taken (no gate fires) and its output stays within the
     tolerance of the exact pass on every element."""
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(7)
-    q, k, v = (torch.randn(2, 16, 4096, 64, generator=g, device="cuda").half() for _ in range(3))
+    q, k, v = (torch.randn(2, 16, 4096, 64, generator=g, device="cuda").to(_tdtype(torch, fmt)) for _ in range(3))
     a = fa.fa_forward(q, k, v, algo=24)
     b = fa.fa_forward(q, k, v, algo=23)
     c = fa.fa_forward(q, k, v, algo=22)
     torch.cuda.synchronize()
-    assert float((a - b).abs().max()) <= 2e-3 and float((c - b).abs().max()) <= 2e-3
-    _sampled_rows_check(fa, oracle, torch, q, k, v, a, 0, [(0, 0, 0, 32), (1, 15, 4064, 32), (1, 7, 2000, 16)], "folded pass")
+    tol = 2e-3 if fmt == 0 else 6e-3
+    assert float((a - b).abs().max()) <= tol and float((c - b).abs().max()) <= tol
+    _sampled_rows_check(fa, oracle, torch, q, k, v, a, fmt, [(0, 0, 0, 32), (1, 15, 4064, 32), (1, 7, 2000, 16)], "folded pass")
 
 
 def test_bench_two_rank_rehearsal():
