@@ -483,6 +483,8 @@ hipError_t w64_dispatch(const void* Q, const void* K, const void* V, void* O,
 hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                          hipStream_t stream);
+hipError_t rp16_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
+                                int BH, int N, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream);
 hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
                          hipStream_t stream);
@@ -596,12 +598,18 @@ hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, 
     if (!Q || !K || !V || !O) return hipErrorInvalidValue;
     if (BH <= 0 || N <= 0 || D <= 0 || D % 16 != 0 || D > kGenMaxD) return hipErrorInvalidValue;
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
-    if (algo != 0 && algo != 1 && algo != 2 && algo != 6 && algo != 13) return hipErrorInvalidValue;
+    if (algo != 0 && algo != 1 && algo != 2 && algo != 6 && algo != 13 && algo != 24) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     // algo 13: the 64-rows-per-wave kernel with the mask; measured 3-4 % SLOWER than the plain tiled kernel
     // under the mask (B8 H16 N4096 d64: 0.462 vs 0.443 ms; N8192 d128: 2.41 vs 2.36 ms), so AUTO stays tiled.
     if (algo == 13)
         return w64_causal_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+    // the pipeline under the mask (fa_fwd_rp16.hip): B8 H16 N4096 d64 fp16 0.309 ms against 0.369 for the tiled kernel (bf16 0.349 /
+    // 0.364), N8192 d128 2.00 against 2.29 ms -- AUTO wherever the grid gives every CU a workgroup, else the tiled kernel
+    if (algo == 0 && (D == 64 || D == 128) && N > 256 &&
+        (long long)BH * ((N + (D == 64 ? 511 : 255)) / (D == 64 ? 512 : 256)) >= device_cus())
+        algo = 24;
+    if (algo == 24) return rp16_causal_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_causal_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
                               : dispatch_causal_d<F16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);

@@ -68,7 +68,12 @@ constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
 // so every wave issues the DMA for its own eighth of the tile and the hand-off is the counted wait + the tile barrier.
 // D = head dim (64 or 128); X = 16-row query blocks per wave (4 at D = 64: 64 rows, 512-row workgroups; 2 at D = 128: 32 rows,
 // 256-row workgroups).  A step always is 32 matrix instructions: 2*D/32 K fragments and D/16 V^T fragments, each feeding X blocks.
-template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false>
+// kCausal: query row i attends to keys 0..i.  A workgroup runs the tiles up to its last row's diagonal; the tiles its row
+// range crosses go through the masked copy of the step (key > row -> -inf), the ones before it through the branch-free
+// loop.  Waves are not skipped individually (the pipeline is shared), which costs the upper rows' waves ~3.5 masked tiles
+// per item; query blocks alternate direction from one round of the persistent grid to the next (last-to-first, then
+// first-to-last), so that every CU's items add up to the same number of tiles.
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false>
 __global__ __launch_bounds__(64 * rp16::kW, 2)
 void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
@@ -149,13 +154,28 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
     const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const unsigned bh = wgid / (unsigned)nqb;
-    const unsigned qb = wgid - bh * (unsigned)nqb;
+    const unsigned qbi = wgid - bh * (unsigned)nqb;
+    unsigned qb = qbi;
+    if constexpr (kCausal) {
+        // Alternate the direction of the query blocks from one round of the persistent grid to the next, so that a CU's
+        // items add up to about the same number of tiles.  The direction must be a function of the HEAD alone (all its
+        // query blocks flip together, else two items would compute the same block): take the round of the head's first
+        // item, found through the inverse of the XCD remap above.
+        const unsigned t0 = bh * (unsigned)nqb, big = xr * (xq + 1u);
+        const unsigned x0 = t0 < big ? t0 / (xq + 1u) : xr + (t0 - big) / (xq ? xq : 1u);
+        const unsigned start0 = x0 < xr ? x0 * (xq + 1u) : big + (x0 - xr) * xq;
+        const unsigned bid0 = 8u * (t0 - start0) + x0;
+        if (((bid0 / gridDim.x) & 1u) == 0u) qb = (unsigned)nqb - 1u - qbi;
+    }
     const size_t head_elems = (size_t)N * D;
     const unsigned head_bytes = (unsigned)(head_elems * 2);
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
     const unsigned q_row0 = qb * kRows + wave * (16u * X) + c16;   // row of block 0; block x is 16x rows further
+    // causal: tiles [0, nt) with nt up to the diagonal of the workgroup's last (existing) row; tiles >= jc cross its row range
+    const int nt = kCausal ? min(ntiles, (int)(min((unsigned)N - 1u, qb * kRows + kRows - 1u) / kBlockN) + 1) : ntiles;
+    const int jc = kCausal ? (int)((qb * kRows) / kBlockN) : nt;
 
     u32x4 qf[X][kKS];   // B operand of QK^T: Q[row of block x][32 ks + 8 g .. +7]
     int q_bad = 0;
@@ -227,14 +247,16 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, h_q, (f >> 1) / kKS, (f >> 1) % kKS);
         else frag[f % kRing] = read_vf(so_v, h_v, f >> 1);
     };
-    auto mask_unit = [&](int tile, int h, f32x4 (&s)[X][2]) {   // keys >= N -> -inf (p = 0)
+    auto mask_unit = [&](int tile, int h, f32x4 (&s)[X][2]) {   // keys >= N (causal: keys after the query) -> -inf (p = 0)
 #pragma unroll
         for (int x = 0; x < X; ++x)
 #pragma unroll
             for (int kbl = 0; kbl < 2; ++kbl)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (tile * kBlockN + 32 * h + 16 * kbl + 4 * (int)g + i >= N) s[x][kbl][i] = -INFINITY;
+                for (int i = 0; i < 4; ++i) {
+                    const int key = tile * kBlockN + 32 * h + 16 * kbl + 4 * (int)g + i;
+                    if (key >= N || (kCausal && (unsigned)key > q_row0 + 16u * x)) s[x][kbl][i] = -INFINITY;
+                }
     };
     auto row_max = [&](const f32x4 (&s)[2]) -> float {   // this row's 32 keys of the unit, unscaled
         const float a = max3(s[0][0], s[0][1], s[0][2]), b = max3(s[1][0], s[1][1], s[1][2]);
@@ -335,7 +357,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
             for (int x = 0; x < X; ++x) o[x][db] = M::mfma(vf, pk_prev[x], o[x][db]);
         }
-        if (partial && tile + 1 == ntiles) mask_unit(tile, h, s_cur);
+        if ((partial && tile + 1 == ntiles) || (kCausal && tile >= jc)) mask_unit(tile, h, s_cur);
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             const float tmax = row_max(s_cur[x]) * c;
@@ -438,7 +460,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             f32x4 s0[X][2];
 #pragma unroll
             for (int x = 0; x < X; ++x) { s0[x][0] = sA[x][0]; s0[x][1] = sA[x][1]; }
-            if (partial && ntiles == 1) mask_unit(0, 0, s0);
+            if ((partial && ntiles == 1) || (kCausal && jc == 0)) mask_unit(0, 0, s0);
             if constexpr (kFast) {   // one reference for the wave; the folded scores already carry the scale
                 float mw = -INFINITY;
 #pragma unroll
@@ -490,7 +512,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             __syncthreads();
         };
         if constexpr (kTrack) {
-            for (int j = 0; j < ntiles; ++j) tile_iter(j, no);
+            for (int j = 0; j < nt; ++j) tile_iter(j, no);
+        } else if constexpr (kCausal) {
+            for (int j = 0; j < jc; ++j) tile_iter(j, no);
+            for (int j = jc; j < nt; ++j) tile_iter(j, yes);
         } else {
             const int nfull = partial ? ntiles - 1 : ntiles;
             for (int j = 0; j < nfull; ++j) tile_iter(j, no);
@@ -502,7 +527,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
         // ---- epilogue: O^T += V(last tile, half 1)^T.P^T ----
         {
-            const unsigned so = ((unsigned)(ntiles - 1) & 3u) * kSlotBytes;
+            const unsigned so = ((unsigned)(nt - 1) & 3u) * kSlotBytes;
 #pragma unroll
             for (int db = 0; db < kDB; ++db) {
                 const u32x4 vf = read_vf(so, 1, db);
@@ -525,7 +550,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             l_row[x] = across_sum(l_part[x]);
-            bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo) || !(fabsf(m_ref[x]) <= kFoldMax);
+            // causal: a row only has row+1 keys to add up
+            const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)N, q_row0 + 16u * x + 1u) * 0x1p-14f : lo;
+            bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo_x) || !(fabsf(m_ref[x]) <= kFoldMax);
         }
         bad = bad || q_bad != 0 || !(k_amax <= 65504.0f);
     } else {
@@ -567,7 +594,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false>
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false>
 static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
@@ -579,7 +606,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const long long cap = device_cus();
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma>;
+    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma, kCausal>;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
     if (attr != hipSuccess) return attr;
     FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
@@ -637,6 +664,35 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                               : launch_rp16<BF16, 64, 4, false, true>(Q, K, V, O, BH, N, scale, stream);
     return out_dtype == 0 ? launch_rp16<BF16, 64, 4, true, false>(Q, K, V, O, BH, N, scale, stream)
                           : launch_rp16<BF16, 64, 4, false, false>(Q, K, V, O, BH, N, scale, stream);
+}
+
+// Causal forward on the pipeline (folded fast pass for both input types), D in {64, 128}.
+hipError_t rp16_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
+                                int BH, int N, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream)
+{
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
+    if ((unsigned long long)(N + 64 * rp16::kW + 3 * kBlockN) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
+    const bool fold = (scale == scale) && scale * kLog2e != 0.0f;
+#define RP16_C(T, DD, XX, OUT, FOLD) return launch_rp16<T, DD, XX, OUT, FOLD, false, true>(Q, K, V, O, BH, N, scale, stream)
+    if (D == 64) {
+        if (in_dtype == 0) {
+            if (fold) { if (out_dtype == 0) RP16_C(F16, 64, 4, true, true); RP16_C(F16, 64, 4, false, true); }
+            if (out_dtype == 0) RP16_C(F16, 64, 4, true, false);
+            RP16_C(F16, 64, 4, false, false);
+        }
+        if (fold) { if (out_dtype == 0) RP16_C(BF16, 64, 4, true, true); RP16_C(BF16, 64, 4, false, true); }
+        if (out_dtype == 0) RP16_C(BF16, 64, 4, true, false);
+        RP16_C(BF16, 64, 4, false, false);
+    }
+    if (in_dtype == 0) {
+        if (fold) { if (out_dtype == 0) RP16_C(F16, 128, 2, true, true); RP16_C(F16, 128, 2, false, true); }
+        if (out_dtype == 0) RP16_C(F16, 128, 2, true, false);
+        RP16_C(F16, 128, 2, false, false);
+    }
+    if (fold) { if (out_dtype == 0) RP16_C(BF16, 128, 2, true, true); RP16_C(BF16, 128, 2, false, true); }
+    if (out_dtype == 0) RP16_C(BF16, 128, 2, true, false);
+    RP16_C(BF16, 128, 2, false, false);
+#undef RP16_C
 }
 
 }  // namespace fa

@@ -82,7 +82,8 @@ int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
  * "next" row of SURVEY.md 8(f) (cf. the runtime-M tail masking of
  * flashattn_warp_spc/flashattn_streaming_16x16_mw_v12d.cu:100-135).  algo: FA_ALGO_AUTO,
  * FA_ALGO_GENERIC, FA_ALGO_TILED (256-row workgroups), 6 (the tiled kernel with 128-row workgroups, two
- * per CU) or FA_ALGO_W64; the last three need D in {64,128}. */
+ * per CU), FA_ALGO_W64 or FA_ALGO_RP16_FOLD (the pipeline under the mask; AUTO's choice whenever the grid gives
+ * every CU a workgroup); the last four need D in {64,128}. */
 int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                       int B, int H, int N, int d, float scale,
                       int in_dtype, int out_dtype, int algo, void* stream);

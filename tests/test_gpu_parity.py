@@ -330,7 +330,7 @@ def test_causal_vs_oracle(fa, oracle, torch_cuda, fmt):
         for n in (1, 17, 64, 65, 255, 256, 257, 600):
             (q, k, v), (qb, kb, vb) = oracle.make_qkv(3, n, d, fmt=fmt, seed=900 + n + d)
             want = oracle.forward(q, k, v, causal=True, nthreads=8)
-            for algo in ((0, 1, 2, 6, 13) if d in (64, 128) else (0, 1)):
+            for algo in ((0, 1, 2, 6, 13, 24) if d in (64, 128) else (0, 1)):
                 got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt, algo=algo)
                 _check(oracle, got, want, fmt, f"causal d={d} n={n} algo={algo} fmt={fmt}")
             got = _run_causal(fa, torch_cuda, qb, kb, vb, fmt, out_same=True)
@@ -764,3 +764,24 @@ def test_native_harness_check_step():
         rel, mab = float(m.group(1)), float(m.group(2))
         assert rel <= tol_rel and mab <= tol_abs, (args, rel, mab)
         assert "TFLOPS" in out.stdout
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_causal_large_grid_item_order(fa, oracle, torch_cuda, fmt):
+    """The causal pipeline alternates the direction of the query blocks between rounds of its persistent grid: with more
+    items than CUs every (head, query block) must still be computed exactly once (found by the randomised sweep: a
+    direction that depended on the round of the ITEM computed some blocks twice and others never)."""
+    torch = torch_cuda
+    for (bh, n, d) in ((300, 1000, 64), (300, 1000, 128), (700, 600, 64)):
+        g = torch.Generator(device="cuda").manual_seed(3 + bh + d)
+        q, k, v = (torch.randn(bh, n, d, generator=g, device="cuda").to(_tdtype(torch, fmt)) for _ in range(3))
+        for algo in (0, 24):
+            o = fa.fa_forward(q, k, v, algo=algo, causal=True)
+            s = (q.float() @ k.float().transpose(1, 2)) * (1.0 / d ** 0.5)
+            s = s.masked_fill(~torch.ones(n, n, dtype=torch.bool, device="cuda").tril_(), float("-inf"))
+            want = torch.softmax(s, dim=-1) @ v.float()
+            err = float((o - want).abs().max())
+            assert err <= MAX_ABS * (1.0 if fmt == 0 else 2.0), (bh, n, d, algo, err)
+            del s, want, o
+        del q, k, v
+        torch.cuda.empty_cache()
