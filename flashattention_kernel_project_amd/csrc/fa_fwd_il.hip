@@ -319,13 +319,22 @@ void fa_fwd_il_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         //            and (last six steps) three max chains over S(t+1).
         const float neg_m = -m_ref;
         float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, ls0 = 0.0f, ls1 = 0.0f;
-        const f32x2 c2 = {c, c}, neg_m2 = {neg_m, neg_m};
-        auto fma_pair = [&](auto jc) {   // one v_pk_fma_f32 for the two scores of the pair
+#ifndef FA_IL_PKFMA
+#define FA_IL_PKFMA 0   // 1: one v_pk_fma_f32 per pair (round 1).  Packed fp32 stalls behind the matrix pipe when it is issued
+                        // between MFMAs (slot model: 81 vs 45.5 cycles per slot), so the interleaved stream uses two v_fma_f32
+#endif
+        auto fma_pair = [&](auto jc) {
             constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;
-            f32x2 x = {s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]};
-            x = __builtin_elementwise_fma(x, c2, neg_m2);
-            s_cur[e0 >> 4][e0 & 15] = x[0];
-            s_cur[e1 >> 4][e1 & 15] = x[1];
+            if constexpr (FA_IL_PKFMA) {
+                const f32x2 c2 = {c, c}, neg_m2 = {neg_m, neg_m};
+                f32x2 x = {s_cur[e0 >> 4][e0 & 15], s_cur[e1 >> 4][e1 & 15]};
+                x = __builtin_elementwise_fma(x, c2, neg_m2);
+                s_cur[e0 >> 4][e0 & 15] = x[0];
+                s_cur[e1 >> 4][e1 & 15] = x[1];
+            } else {
+                s_cur[e0 >> 4][e0 & 15] = __builtin_fmaf(s_cur[e0 >> 4][e0 & 15], c, neg_m);
+                s_cur[e1 >> 4][e1 & 15] = __builtin_fmaf(s_cur[e1 >> 4][e1 & 15], c, neg_m);
+            }
         };
         auto exp_pair = [&](auto jc) {
             constexpr int e0 = 2 * decltype(jc)::value, e1 = e0 + 1;

@@ -534,9 +534,11 @@ const char* algo_kernel_name(int algo, int D)
         case 1: return "fa::fa_fwd_generic_kernel";
         case 2: return (D == 64 || D == 128) ? "fa::fa_fwd_kernel" : "fa::fa_fwd_generic_kernel";
         case 5: case 6: return "fa::fa_fwd_il_kernel";
+#ifdef FA_EXPERIMENTS
         case 13: return "fa::fa_fwd_w64_kernel";
         case 16: return "fa::fa_fwd_w64x_kernel";
         case 21: case 22: return "fa::fa_fwd_rp_kernel";
+#endif
         case 23: case 24: case 25: return "fa::fa_fwd_rp16_kernel";
         default: return "";
     }
@@ -556,13 +558,13 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 0) algo = auto_algo(BH, N, D, in_dtype);
     if (algo == 5) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 8, stream);
     if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
-    if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 21) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
-    if (algo == 22) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
     if (algo == 23) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 24) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
 #ifdef FA_EXPERIMENTS
+    if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);    // round 1's defaults and the
+    if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);   // 32x32x16 pipeline: A/B baselines
+    if (algo == 21) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
+    if (algo == 22) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
     if (algo == 25) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 3, stream);   // 24 with LDS-DMA staging
     if (algo >= 17 && algo <= 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
     if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
@@ -579,7 +581,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
 #else
-    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 12) || algo == 14 || algo == 15 || (algo >= 17 && algo <= 20) || algo > 24) return hipErrorInvalidValue;
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo > 24) return hipErrorInvalidValue;
 #endif
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
@@ -602,8 +604,12 @@ hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, 
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     // algo 13: the 64-rows-per-wave kernel with the mask; measured 3-4 % SLOWER than the plain tiled kernel
     // under the mask (B8 H16 N4096 d64: 0.462 vs 0.443 ms; N8192 d128: 2.41 vs 2.36 ms), so AUTO stays tiled.
+#ifdef FA_EXPERIMENTS
     if (algo == 13)
         return w64_causal_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
+#else
+    if (algo == 13) return hipErrorInvalidValue;
+#endif
     // the pipeline under the mask (fa_fwd_rp16.hip): B8 H16 N4096 d64 fp16 0.309 ms against 0.369 for the tiled kernel (bf16 0.349 /
     // 0.364), N8192 d128 2.00 against 2.29 ms -- AUTO wherever the grid gives every CU a workgroup, else the tiled kernel
     if (algo == 0 && (D == 64 || D == 128) && N > 256 &&

@@ -36,15 +36,17 @@ extern "C" {
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
 #define FA_ALGO_INTERLEAVED     5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
 #define FA_ALGO_INTERLEAVED_2WG 6 /* the same with 128-row workgroups, two per CU, D = 64 */
-#define FA_ALGO_W64            13 /* 64 query rows per wave (d=64) / 32 (d=128), phase-ordered stream on 32x32x16, persistent grid */
-#define FA_ALGO_W64X           16 /* the W64 stream on v_mfma_f32_16x16x32: four (d=64) / two (d=128) 16-row blocks per wave share every fragment */
-#define FA_ALGO_RP             21 /* rolling half-tile pipeline, branch-free steady state, single-instruction fp32 vector work, D in {64,128} */
-#define FA_ALGO_RP_FOLD        22 /* RP with the folded fast pass (scale folded into a rounded Q, wave reference max as accumulator
-                                     start; exact tracked pass as fallback), fp16 at D = 64; other inputs run RP */
-#define FA_ALGO_RP16           23 /* RP on v_mfma_f32_16x16x32 (four 16-row blocks per wave at D = 64, two at D = 128), exact passes */
-#define FA_ALGO_RP16_FOLD      24 /* RP16 with the folded fast pass (fp16; bf16 with K converted to fp16 while it is staged) */
+#define FA_ALGO_RP16           23 /* rolling half-tile pipeline on v_mfma_f32_16x16x32 (four 16-row blocks per wave at D = 64, two at D = 128),
+                                     branch-free steady state, single-instruction fp32 vector work, exact passes */
+#define FA_ALGO_RP16_FOLD      24 /* RP16 with the folded fast pass: scale folded into a rounded Q, the wave's reference max as the
+                                     accumulators' start value (bf16: K converted to fp16 while it is staged); exact tracked pass
+                                     as the per-workgroup fallback */
 /* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
  * A/B kernels that AUTO never selects. */
+#define FA_ALGO_W64            13 /* round 1's default for bf16: 64 query rows per wave, phase-ordered stream on 32x32x16, packed fp32 */
+#define FA_ALGO_W64X           16 /* round 1's default for fp16: the W64 stream on v_mfma_f32_16x16x32 */
+#define FA_ALGO_RP             21 /* the rolling pipeline on 32x32x16 (two 32-row blocks per wave), exact passes */
+#define FA_ALGO_RP_FOLD        22 /* RP with the folded fast pass (fp16, D = 64) */
 #define FA_ALGO_PIPE            3 /* TILED with QK^T of tile t+1 under the softmax of tile t, D = 64 */
 #define FA_ALGO_PINGPONG        4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
 #define FA_ALGO_TLP3            9 /* simple per-wave stream, three 128-row workgroups per CU, D = 64 */
@@ -82,8 +84,8 @@ int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
  * "next" row of SURVEY.md 8(f) (cf. the runtime-M tail masking of
  * flashattn_warp_spc/flashattn_streaming_16x16_mw_v12d.cu:100-135).  algo: FA_ALGO_AUTO,
  * FA_ALGO_GENERIC, FA_ALGO_TILED (256-row workgroups), 6 (the tiled kernel with 128-row workgroups, two
- * per CU), FA_ALGO_W64 or FA_ALGO_RP16_FOLD (the pipeline under the mask; AUTO's choice whenever the grid gives
- * every CU a workgroup); the last four need D in {64,128}. */
+ * per CU) or FA_ALGO_RP16_FOLD (the pipeline under the mask; AUTO's choice whenever the grid gives every CU a
+ * workgroup); the last three need D in {64,128}.  (FA_ALGO_W64 under the mask: experimental build only.) */
 int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                       int B, int H, int N, int d, float scale,
                       int in_dtype, int out_dtype, int algo, void* stream);
