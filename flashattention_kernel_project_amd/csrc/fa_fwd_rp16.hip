@@ -49,7 +49,8 @@ constexpr int kW = 8;
 #endif
 constexpr int kAhead = FA_RP16_AHEAD;   // fragments read ahead of their MFMAs (at most kRing - 1)
 constexpr int kRing = 4;           // fragment registers (8 fragments per step)
-constexpr float kHeadroom = 4.0f;
+constexpr float kHeadroom = 4.0f;      // exact optimistic pass: reference = the row's max over its first 32 keys + this
+constexpr float kHeadroomFold = 1.0f;  // folded pass: the reference already is the maximum over the wave's 64 rows
 constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
 #ifndef FA_RP16_RUNSUM
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
@@ -407,7 +408,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     };
 
     // mode 0: folded fast pass; 1: exact, reference max fixed after the first 32 keys; 2: exact, lazy running max
-    auto run = [&](auto mode_c) __attribute__((always_inline)) {
+    // returns true when the folded pass gave up right after its reference was known (nothing computed yet)
+    auto run = [&](auto mode_c) __attribute__((always_inline)) -> bool {
         constexpr int kMode = decltype(mode_c)::value;
         constexpr bool kTrack = kMode == 2, kFast = kMode == 0;
         const std::integral_constant<bool, kFast> fast_c{};
@@ -467,9 +469,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 for (int x = 0; x < X; ++x) mw = fmaxf(mw, row_max(s0[x]));
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) mw = fmaxf(mw, __shfl_xor(mw, off, 64));
-                mw += kHeadroom;
+                mw += kHeadroomFold;
 #pragma unroll
                 for (int x = 0; x < X; ++x) m_ref[x] = mw;
+                // the gates that are known now (reference beyond kFoldMax, folded Q out of range) end the pass before it costs
+                // anything: one workgroup vote per item
+                if (__syncthreads_or((!(fabsf(mw) <= kFoldMax) || q_bad != 0) ? 1 : 0)) return true;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) minit[i] = -mw;
 #pragma unroll
@@ -535,6 +540,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 for (int x = 0; x < X; ++x) o[x][db] = M::mfma(vf, pkB[x], o[x][db]);
             }
         }
+        return false;
     };
 
     float l_row[X];
@@ -543,18 +549,33 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     if constexpr (kFold) {
         k_amax = 0.0f;
         load_q(yes);
-        run(std::integral_constant<int, 0>{});
-        // fp16 weights: subnormal ones must add up to < 2^-11 of the row; bf16 weights only must not vanish in fp32 (a row
-        // more than ~100 log2 units below its wave's reference: p = 0, l = 0)
-        const float lo = T::id == 0 ? (float)N * 0x1p-14f : 0x1p-100f;
+        const bool gave_up = run(std::integral_constant<int, 0>{});
+        // fp16 weights: each subnormal one is off by at most 2^-25, N of them by N * 2^-25 in the worst case (2^-13 * sqrt(N)
+        // typically), which stays below 2^-9 of the row sum; bf16 weights only must not vanish in fp32 (a row more than ~100
+        // log2 units below its wave's reference: p = 0, l = 0)
+        const float lo = T::id == 0 ? (float)N * 0x1p-16f : 0x1p-100f;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             l_row[x] = across_sum(l_part[x]);
             // causal: a row only has row+1 keys to add up
-            const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)N, q_row0 + 16u * x + 1u) * 0x1p-14f : lo;
+            const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)N, q_row0 + 16u * x + 1u) * 0x1p-16f : lo;
             bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo_x) || !(fabsf(m_ref[x]) <= kFoldMax);
         }
-        bad = bad || q_bad != 0 || !(k_amax <= 65504.0f);
+        bad = bad || gave_up || q_bad != 0 || !(k_amax <= 65504.0f);
+        // folded pass refused: the exact optimistic pass first (same pipeline, per-row reference, one v_fma per score --
+        // it is what large logits need; bf16 weights cannot overflow in it), the tracked pass only if that overflows too
+        if (__syncthreads_or(bad ? 1 : 0)) {
+            load_q(no);
+            run(std::integral_constant<int, 1>{});
+            bad = false;
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                l_row[x] = across_sum(l_part[x]);
+                bad = bad || !(l_row[x] < lim);
+            }
+        } else {
+            bad = false;
+        }
     } else {
         load_q(no);
         run(std::integral_constant<int, 1>{});
@@ -565,7 +586,6 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
-        if constexpr (kFold) load_q(no);
         run(std::integral_constant<int, 2>{});
 #pragma unroll
         for (int x = 0; x < X; ++x) l_row[x] = across_sum(l_part[x]);
