@@ -52,6 +52,11 @@ constexpr int kRing = 4;           // fragment registers (8 fragments per step)
 constexpr float kHeadroom = 4.0f;      // exact optimistic pass: reference = the row's max over its first 32 keys + this
 constexpr float kHeadroomFold = 1.0f;  // folded pass: the reference already is the maximum over the wave's 64 rows
 constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
+constexpr float kFoldAim = 6.0f;       // folded pass: log2 of the row sum the reference is placed for
+constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores' maximum it may go (weights stay below 2^16)
+#ifndef FA_RP16_GATES
+#define FA_RP16_GATES 15           // lab only: which refusal gates of the folded pass are armed (1 sum overflow, 2 sum too small, 4 reference, 8 Q range)
+#endif
 #ifndef FA_RP16_RUNSUM
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
@@ -469,7 +474,26 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 for (int x = 0; x < X; ++x) mw = fmaxf(mw, row_max(s0[x]));
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) mw = fmaxf(mw, __shfl_xor(mw, off, 64));
-                mw += kHeadroomFold;
+                if (kCausal || (partial && ntiles == 1)) {
+                    mw += kHeadroomFold;
+                } else {
+                    // Place the reference so that a typical row sum lands mid-window (2^kFoldAim; the window is
+                    // [N 2^-16, 60000) for fp16 weights): the mean weight of these 64 x 32 scores relative to their maximum
+                    // predicts the row sum N * mean * 2^(max - reference).  With the maximum + 1 alone, rows of a wave whose
+                    // first scores hold an outlier fell below the window once the logits spread a little (sigma ~ 3 log2 units).
+                    float e = 0.0f;
+#pragma unroll
+                    for (int x = 0; x < X; ++x)
+#pragma unroll
+                        for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) e += fast_exp2(s0[x][kbl][i] - mw);
+                    e = across_sum(e);
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) e += __shfl_xor(e, off, 64);
+                    const float shift = __builtin_amdgcn_logf((float)N * e * (1.0f / (64.0f * 32.0f))) - kFoldAim;
+                    mw += fminf(fmaxf(shift, -kFoldShiftMin), kFoldMax);
+                }
 #pragma unroll
                 for (int x = 0; x < X; ++x) m_ref[x] = mw;
                 // the gates that are known now (reference beyond kFoldMax, folded Q out of range) end the pass before it costs
@@ -559,9 +583,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             l_row[x] = across_sum(l_part[x]);
             // causal: a row only has row+1 keys to add up
             const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)N, q_row0 + 16u * x + 1u) * 0x1p-16f : lo;
-            bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo_x) || !(fabsf(m_ref[x]) <= kFoldMax);
+            bad = bad || ((FA_RP16_GATES & 1) && !(l_row[x] < lim)) || ((FA_RP16_GATES & 2) && !(l_row[x] >= lo_x)) ||
+                  ((FA_RP16_GATES & 4) && !(fabsf(m_ref[x]) <= kFoldMax));
         }
-        bad = bad || gave_up || q_bad != 0 || !(k_amax <= 65504.0f);
+        bad = bad || gave_up || ((FA_RP16_GATES & 8) && q_bad != 0) || !(k_amax <= 65504.0f);
         // folded pass refused: the exact optimistic pass first (same pipeline, per-row reference, one v_fma per score --
         // it is what large logits need; bf16 weights cannot overflow in it), the tracked pass only if that overflows too
         if (__syncthreads_or(bad ? 1 : 0)) {
@@ -602,7 +627,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
         for (int db = 0; db < kDB; ++db) {
             const unsigned col = 16u * db + 4u * g;
-            const float a = o[x][db][0] * inv, b = o[x][db][1] * inv, cc = o[x][db][2] * inv, d = o[x][db][3] * inv;
+            float a = o[x][db][0] * inv, b = o[x][db][1] * inv, cc = o[x][db][2] * inv, d = o[x][db][3] * inv;
+#ifdef FA_RP16_DIAG
+            if (db == 0 && g == 0) { a = l_row[x]; b = m_ref[x]; }
+#endif
             if constexpr (kOutF32) {
                 const f32x4 v = {a, b, cc, d};
                 buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--H", type=int, default=16)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--spread", type=float, default=1.0, help="scale of Q and K (the logits grow with its square)")
     args = ap.parse_args()
     import torch
     from flashattention_kernel_project_amd import capi
@@ -33,7 +34,8 @@ def main():
         L.fa_forward_ex.restype = C.c_int
         libs.append((os.path.basename(path), L))
     g = torch.Generator(device="cuda").manual_seed(0)
-    q, k, v = (torch.randn(args.B, args.H, args.N, args.d, generator=g, device="cuda").half() for _ in range(3))
+    q, k, v = (torch.randn(args.B, args.H, args.N, args.d, generator=g, device="cuda") for _ in range(3))
+    q, k, v = (q * args.spread).half(), (k * args.spread).half(), v.half()
     outs = [torch.empty(q.shape, device="cuda", dtype=torch.float32) for _ in libs]
     st = torch.cuda.current_stream().cuda_stream
 
