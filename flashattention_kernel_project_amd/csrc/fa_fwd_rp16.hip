@@ -54,9 +54,15 @@ constexpr float kHeadroomFold = 1.0f;  // folded pass: the reference already is 
 constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
 constexpr float kFoldAim = 6.0f;       // folded pass: log2 of the row sum the reference is placed for
 constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores' maximum it may go (weights stay below 2^16)
+#ifndef FA_RP16_ABL
+#define FA_RP16_ABL 0              // lab only (timing ablations, results are garbage): 1 no LDS fragment reads, 2 no softmax vector
+#endif                             // work, 4 no matrix instructions, 8 no K/V staging, 16 no tile barrier
 #ifndef FA_RP16_GATES
 #define FA_RP16_GATES 15           // lab only: which refusal gates of the folded pass are armed (1 sum overflow, 2 sum too small, 4 reference, 8 Q range)
 #endif
+#ifndef FA_RP16_SUMMFMA
+#define FA_RP16_SUMMFMA 1          // 1: the optimistic passes take the row sums from the matrix pipe (one more PV block against a
+#endif                             // fragment of ones: X matrix instructions per step instead of 32 v_add_f32 per lane)
 #ifndef FA_RP16_RUNSUM
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
@@ -231,6 +237,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     u32x4 kst[kLoads], vst[kLoads];
     u32x4 frag[kRing];
     f32x4 minit;   // folded pass: every score chain starts at -(wave reference maximum)
+    // row sums on the matrix pipe: lacc[x][i] = sum over keys of the ROUNDED weights of row (lane & 15) of block x, the
+    // same in every register and every lane group (all 16 "head-dim rows" of the ones fragment are equal)
+    f32x4 lacc[X];
+    u32x4 ones = {T::kOnes2, T::kOnes2, T::kOnes2, T::kOnes2};
+    if constexpr (FA_RP16_SUMMFMA) asm volatile("" : "+v"(ones));   // stays in registers, not re-materialised per use
 
     // K fragment (key block kbl of half h in slot offset so, k-step ks); V^T fragment (head-dim block db) of half h
     auto read_kf = [&](unsigned so, int h, int kbl, int ks) -> u32x4 {
@@ -250,6 +261,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // odd f -> V^T fragment db = f/2 of the PV unit
     auto read_frag = [&](auto fc, unsigned so_q, int h_q, unsigned so_v, int h_v) {
         constexpr int f = decltype(fc)::value;
+        if constexpr ((FA_RP16_ABL & 1) != 0) return;
         if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, h_q, (f >> 1) / kKS, (f >> 1) % kKS);
         else frag[f % kRing] = read_vf(so_v, h_v, f >> 1);
     };
@@ -297,7 +309,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
             const unsigned w = T::pack2(s_cur[x][kbl][e], s_cur[x][kbl][e + 1]);
             pk_cur[x][2 * kbl + (j & 1)] = w;
-            if constexpr (T::kSumRounded) {
+            if constexpr (FA_RP16_SUMMFMA) {
+            } else if constexpr (T::kSumRounded) {
                 ls[x][j & 1] = T::sum2(w, ls[x][j & 1]);
             } else {
                 ls[x][0] += s_cur[x][kbl][e];
@@ -306,12 +319,23 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         };
         auto valu_step = [&](auto jc) {   // skewed: nothing waits on the instruction before it
             constexpr int j = decltype(jc)::value;
+            if constexpr ((FA_RP16_ABL & 2) != 0) {   // keep the scores "used" without an instruction
+                if constexpr (j == 0) {
+#pragma unroll
+                    for (int x = 0; x < X; ++x) asm volatile("" :: "v"(s_cur[x][0]), "v"(s_cur[x][1]));
+                }
+                return;
+            }
             if constexpr (j + 2 < kPairs && !kFast) fma_pair(std::integral_constant<int, j + 2>{});
             if constexpr (j + 1 < kPairs) exp_pair(std::integral_constant<int, j + 1>{});
             fin_pair(jc);
         };
         auto issue_mfma = [&](auto ic) {
             constexpr int i = decltype(ic)::value, f = i / X, x = i % X;
+            if constexpr ((FA_RP16_ABL & 4) != 0) {   // the fragment stays "used"
+                if constexpr (x == 0) asm volatile("" :: "v"(frag[f % kRing]));
+                return;
+            }
             if constexpr ((f & 1) == 0) {
                 constexpr int kbl = (f >> 1) / kKS, ks = (f >> 1) % kKS;
                 using MQ = std::conditional_t<kCvtK && kFast, Mx<F16>, M>;
@@ -322,15 +346,15 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             }
         };
 
-        if constexpr (!kFast) {
+        if constexpr (!kFast && (FA_RP16_ABL & 2) == 0) {
             fma_pair(c0{});
             fma_pair(c1{});
         }
-        exp_pair(c0{});
+        if constexpr ((FA_RP16_ABL & 2) == 0) exp_pair(c0{});
         sfor<32>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT && !kDma) {   // land tile j+2 (requested at the top of the iteration)
+            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
                     lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
@@ -338,6 +362,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 }
             }
             issue_mfma(ic);
+            if constexpr (FA_RP16_SUMMFMA && (FA_RP16_ABL & 4) == 0 && i % (32 / X) == 32 / X - 1)
+                lacc[i / (32 / X)] = M::mfma(ones, pk_prev[i / (32 / X)], lacc[i / (32 / X)]);
             if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
                 constexpr int f = i / X + kAhead;
                 if constexpr (f < kNF) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
@@ -426,6 +452,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             for (int db = 0; db < kDB; ++db) o[x][db] = zero4;
             l_part[x] = 0.0f;
             ls[x][0] = ls[x][1] = 0.0f;
+            lacc[x] = zero4;
             pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of ring slot 3
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
@@ -520,7 +547,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             const unsigned so_m1 = ((unsigned)(j + 3) & 3u) * kSlotBytes, so_0 = ((unsigned)j & 3u) * kSlotBytes;
             const unsigned so_p1 = ((unsigned)(j + 1) & 3u) * kSlotBytes, so_p2 = ((unsigned)(j + 2) & 3u) * kSlotBytes;
             // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
-            if constexpr (kDma) {
+            if constexpr ((FA_RP16_ABL & 8) != 0) {
+            } else if constexpr (kDma) {
                 dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_p2);   // the barrier below waits for it (vmcnt) and publishes it
             } else {
 #pragma unroll
@@ -538,7 +566,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 step(c0{}, masked_c, fast_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p2);
                 step(c1{}, masked_c, fast_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p2);
             }
-            __syncthreads();
+            if constexpr ((FA_RP16_ABL & 16) == 0) __syncthreads();
         };
         if constexpr (kTrack) {
             for (int j = 0; j < nt; ++j) tile_iter(j, no);
@@ -550,7 +578,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             for (int j = 0; j < nfull; ++j) tile_iter(j, no);
             if (partial) tile_iter(ntiles - 1, yes);
         }
-        if constexpr (!kTrack && FA_RP16_RUNSUM) {
+        if constexpr (!kTrack && FA_RP16_RUNSUM && !FA_RP16_SUMMFMA) {
 #pragma unroll
             for (int x = 0; x < X; ++x) l_part[x] = ls[x][0] + ls[x][1];
         }
@@ -562,6 +590,13 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 const u32x4 vf = read_vf(so, 1, db);
 #pragma unroll
                 for (int x = 0; x < X; ++x) o[x][db] = M::mfma(vf, pkB[x], o[x][db]);
+            }
+            if constexpr (!kTrack && FA_RP16_SUMMFMA) {
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    lacc[x] = M::mfma(ones, pkB[x], lacc[x]);
+                    l_part[x] = lacc[x][0] * 0.25f;   // across_sum adds the four lane groups' (equal) copies
+                }
             }
         }
         return false;
@@ -587,6 +622,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                   ((FA_RP16_GATES & 4) && !(fabsf(m_ref[x]) <= kFoldMax));
         }
         bad = bad || gave_up || ((FA_RP16_GATES & 8) && q_bad != 0) || !(k_amax <= 65504.0f);
+        if constexpr (FA_RP16_ABL != 0) bad = false;
         // folded pass refused: the exact optimistic pass first (same pipeline, per-row reference, one v_fma per score --
         // it is what large logits need; bf16 weights cannot overflow in it), the tracked pass only if that overflows too
         if (__syncthreads_or(bad ? 1 : 0)) {
