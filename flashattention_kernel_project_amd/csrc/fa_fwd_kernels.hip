@@ -516,15 +516,27 @@ hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
 // The CU count is read from the current device per call.
 int auto_algo(int BH, int N, int D, int in_dtype)
 {
-    if (D == 64) {
-        const long long cus = device_cus();
-        const long long nwg512 = (long long)BH * ((N + 511) / 512);
-        if (N > 256 && nwg512 >= cus) return 24;   // N <= 256 would leave half of every 512-row workgroup idle
+    if (D != 64 && D != 128) return 1;
+    const long long cus = device_cus();
+    if (D == 64 && N <= 256) {   // a handful of tiles per item: the 16x16x16 interleaved kernels' short prologue wins
         const long long nwg256 = (long long)BH * ((N + 255) / 256);
         return nwg256 >= 2 * cus ? 5 : 6;
     }
-    if (D == 128) return 24;
-    return 1;
+    // The rolling pipeline on the widest waves whose grid still covers the device: rounds of the persistent grid x rows per
+    // workgroup / efficiency of that width (LDS fragment reuse: 1.0 / 0.9 / 0.7 for 64- / 32- / 16-row waves; measured on
+    // B*H x N sweeps, tools/mid_grid_sweep.py -> profiles/r02_mid_grid.txt)
+    const int wide = D == 64 ? 512 : 256;
+    const int ids[3] = {24, 26, 27};
+    const double eff[3] = {1.0, 0.9, 0.7};
+    int best = 24;
+    double best_cost = 0.0;
+    for (int w = 0; w < (D == 64 ? 3 : 2); ++w) {
+        const int rows = wide >> w;
+        const long long nwg = (long long)BH * ((N + rows - 1) / rows);
+        const double cost = (double)((nwg + cus - 1) / cus) * rows / eff[w];
+        if (w == 0 || cost < best_cost) { best = ids[w]; best_cost = cost; }
+    }
+    return best;
 }
 
 // Name of the kernel template an explicit algo id launches (rocprofv3 kernel-trace names start with it).
@@ -539,7 +551,7 @@ const char* algo_kernel_name(int algo, int D)
         case 16: return "fa::fa_fwd_w64x_kernel";
         case 21: case 22: return "fa::fa_fwd_rp_kernel";
 #endif
-        case 23: case 24: case 25: return "fa::fa_fwd_rp16_kernel";
+        case 23: case 24: case 25: case 26: case 27: return "fa::fa_fwd_rp16_kernel";
         default: return "";
     }
 }
@@ -560,6 +572,10 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (algo == 23) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 24) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
+    if (algo == 26 || algo == 27) {   // the pipeline on half-width / quarter-width waves (32 / 16 rows at D = 64, 16 at D = 128)
+        if (D != 64 && !(D == 128 && algo == 26)) return hipErrorInvalidValue;
+        return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1 | (algo == 26 ? 4 : 8), stream);
+    }
 #ifdef FA_EXPERIMENTS
     if (algo == 13) return w64_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);    // round 1's defaults and the
     if (algo == 16) return w64x_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);   // 32x32x16 pipeline: A/B baselines
@@ -581,7 +597,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 9 || algo == 10)
         return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
 #else
-    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo > 24) return hipErrorInvalidValue;
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo == 25 || algo > 27) return hipErrorInvalidValue;
 #endif
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)

@@ -47,8 +47,7 @@ constexpr int kW = 8;
 #ifndef FA_RP16_AHEAD
 #define FA_RP16_AHEAD 2
 #endif
-constexpr int kAhead = FA_RP16_AHEAD;   // fragments read ahead of their MFMAs (at most kRing - 1)
-constexpr int kRing = 4;           // fragment registers (8 fragments per step)
+constexpr int kAheadWide = FA_RP16_AHEAD;   // 64-row waves: fragments read ahead of their MFMAs (at most ring - 1), ring of 4 registers
 constexpr float kHeadroom = 4.0f;      // exact optimistic pass: reference = the row's max over its first 32 keys + this
 constexpr float kHeadroomFold = 1.0f;  // folded pass: the reference already is the maximum over the wave's 64 rows
 constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
@@ -67,7 +66,7 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
 #ifndef FA_RP16_STAGE_SLOT
-#define FA_RP16_STAGE_SLOT 16      // matrix slot of the second step in front of which tile j+2 is written to LDS
+#define FA_RP16_STAGE_SLOT 16      // matrix slot (of 32; scaled for narrower steps) of the second step in front of which tile j+2 is written to LDS
 #endif
 }  // namespace rp16
 
@@ -104,7 +103,13 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr int kRows = 16 * X * kW;
     constexpr int kKS = D / 32, kDB = D / 16;   // k-steps of QK^T, 16-row blocks of O^T
     constexpr int kNF = 2 * kKS + kDB;          // fragments per step (K and V^T alternate: 2 kKS == kDB)
-    static_assert(2 * kKS == kDB && kNF * X == 32 && kNF % kRing == 0, "a step is 32 matrix instructions");
+    // fragment registers and read-ahead: a fragment feeds X matrix instructions, so the narrow waves (X < 4 at D = 64: small
+    // grids) need more of them in flight to cover the LDS latency
+    constexpr bool kWide = 16 * X * (D / 64) >= 64;
+    constexpr int kRing = kWide ? 4 : 8;
+    constexpr int kAhead = kWide ? kAheadWide : (X == 2 ? 4 : 6);
+    constexpr int kSlots = kNF * X;             // matrix instructions per step (32 for the 64-row waves: X = 4 at D = 64, 2 at D = 128)
+    static_assert(2 * kKS == kDB && kNF % kRing == 0 && kSlots % (4 * X) == 0, "fragment ring / vector pair-steps divide a step");
     constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);   // 16-B chunks of K (and of V) per thread and tile
     constexpr unsigned kRowB = D * 2;
     constexpr unsigned kTile = kBlockN * D * 2;
@@ -351,10 +356,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             fma_pair(c1{});
         }
         if constexpr ((FA_RP16_ABL & 2) == 0) exp_pair(c0{});
-        sfor<32>([&](auto ic) {
+        sfor<kSlots>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
+            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT * kSlots / 32 && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
                     lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
@@ -362,14 +367,14 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 }
             }
             issue_mfma(ic);
-            if constexpr (FA_RP16_SUMMFMA && (FA_RP16_ABL & 4) == 0 && i % (32 / X) == 32 / X - 1)
-                lacc[i / (32 / X)] = M::mfma(ones, pk_prev[i / (32 / X)], lacc[i / (32 / X)]);
+            if constexpr (FA_RP16_SUMMFMA && (FA_RP16_ABL & 4) == 0 && i % kNF == kNF - 1)
+                lacc[i / kNF] = M::mfma(ones, pk_prev[i / kNF], lacc[i / kNF]);
             if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
                 constexpr int f = i / X + kAhead;
                 if constexpr (f < kNF) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
                 else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
             }
-            constexpr int kPer = 32 / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
+            constexpr int kPer = kSlots / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
             if constexpr (i % kPer == kPer - 1) valu_step(std::integral_constant<int, i / kPer>{});
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -518,7 +523,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     e = across_sum(e);
 #pragma unroll
                     for (int off = 1; off < 16; off <<= 1) e += __shfl_xor(e, off, 64);
-                    const float shift = __builtin_amdgcn_logf((float)N * e * (1.0f / (64.0f * 32.0f))) - kFoldAim;
+                    const float shift = __builtin_amdgcn_logf((float)N * e * (1.0f / (16.0f * X * 32.0f))) - kFoldAim;
                     mw += fminf(fmaxf(shift, -kFoldShiftMin), kFoldMax);
                 }
 #pragma unroll
@@ -707,8 +712,18 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
     if (D != 64 && D != 128) return hipErrorInvalidValue;
     if ((unsigned long long)(N + 64 * rp16::kW + 3 * kBlockN) * (unsigned)D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     const bool dma = (fold & 2) != 0;
+    const int narrow = (fold >> 2) & 3;   // 1: half-width waves (32 rows at D = 64, 16 at D = 128), 2: quarter-width (16 rows, D = 64)
     fold &= 1;
     if (!(scale == scale) || scale * kLog2e == 0.0f) fold = 0;
+    if (D == 128 && narrow) {   // 16-row waves (128-row workgroups) for small grids
+        if (dma || narrow != 1) return hipErrorInvalidValue;
+#define RP16_N(T, OUT) return fold ? launch_rp16<T, 128, 1, OUT, true>(Q, K, V, O, BH, N, scale, stream) \
+                                   : launch_rp16<T, 128, 1, OUT, false>(Q, K, V, O, BH, N, scale, stream)
+        if (in_dtype == 0) { if (out_dtype == 0) RP16_N(F16, true); RP16_N(F16, false); }
+        if (out_dtype == 0) RP16_N(BF16, true);
+        RP16_N(BF16, false);
+#undef RP16_N
+    }
     if (D == 128) {
         if (dma) return hipErrorInvalidValue;
         if (in_dtype == 0 && fold)
@@ -722,6 +737,20 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                                   : launch_rp16<BF16, 128, 2, false, true>(Q, K, V, O, BH, N, scale, stream);
         return out_dtype == 0 ? launch_rp16<BF16, 128, 2, true, false>(Q, K, V, O, BH, N, scale, stream)
                               : launch_rp16<BF16, 128, 2, false, false>(Q, K, V, O, BH, N, scale, stream);
+    }
+    if (narrow) {   // small grids: the same pipeline on narrower waves (folded pass first, both input types)
+        if (dma || narrow > 2) return hipErrorInvalidValue;
+#define RP16_N(T, XX, OUT) return fold ? launch_rp16<T, 64, XX, OUT, true>(Q, K, V, O, BH, N, scale, stream) \
+                                       : launch_rp16<T, 64, XX, OUT, false>(Q, K, V, O, BH, N, scale, stream)
+        if (narrow == 1) {
+            if (in_dtype == 0) { if (out_dtype == 0) RP16_N(F16, 2, true); RP16_N(F16, 2, false); }
+            if (out_dtype == 0) RP16_N(BF16, 2, true);
+            RP16_N(BF16, 2, false);
+        }
+        if (in_dtype == 0) { if (out_dtype == 0) RP16_N(F16, 1, true); RP16_N(F16, 1, false); }
+        if (out_dtype == 0) RP16_N(BF16, 1, true);
+        RP16_N(BF16, 1, false);
+#undef RP16_N
     }
 #ifndef FA_EXPERIMENTS
     if (dma) return hipErrorInvalidValue;   // the LDS-DMA variant lost the A/B (0.552 vs 0.508 ms): experimental build only

@@ -49,8 +49,8 @@ def _have_exp():
 
 
 def _algos_for(d):
-    algos = ((0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25) if d == 64
-             else ((0, 1, 2, 4, 13, 14, 15, 16, 21, 23, 24) if d == 128 else (0, 1)))
+    algos = ((0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27) if d == 64
+             else ((0, 1, 2, 4, 13, 14, 15, 16, 21, 23, 24, 26) if d == 128 else (0, 1)))
     return tuple(a for a in algos if a not in _EXPERIMENTAL or _have_exp())
 
 
@@ -300,7 +300,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     # 13, 14) sum the ROUNDED bf16 weights instead and meet the plain bar; the A/B variants do not.
     def tol(algo):
         return MAX_ABS * (2.0 if fmt == 1 and algo in (9, 11, 12) else 1.0)
-    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27) if a not in _EXPERIMENTAL or _have_exp()):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol(algo))
     # ragged N with the overflow in the partial last tile
@@ -309,7 +309,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     k2[0, n2 - 1] = q2[0, 200] * 40.0
     q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
     want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
-    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27) if a not in _EXPERIMENTAL or _have_exp()):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
         _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol(algo))
 
@@ -591,7 +591,7 @@ def test_cfg3_exact_shape_through_auto(fa, oracle, torch_cuda):
     torch = torch_cuda
     (q, k, v), (qb, kb, vb) = oracle.make_qkv(32, 1024, 64, 0, seed=303)
     sel = fa.lib().fa_selected_algo(4, 8, 1024, 64, 0)
-    assert sel in (5, 6), sel
+    assert sel == 27, sel   # 256 workgroups of 128 rows: the pipeline on 16-row waves
     Q, K, V = (_to_dev(torch, x, 0).view(4, 8, 1024, 64) for x in (qb, kb, vb))
     o = fa.fa_forward(Q, K, V)
     torch.cuda.synchronize()
@@ -623,13 +623,15 @@ def test_cfg5_per_gpu_full_size(fa, oracle, torch_cuda, fmt):
 
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_auto_dispatch_boundaries(fa, oracle, torch_cuda, fmt):
-    """FA_ALGO_AUTO at d=64 switches kernels where the grid reaches one 512-row workgroup per CU and two 256-row
-    workgroups per CU: one shape on each side of both thresholds, through algo 0, against the oracle."""
+    """FA_ALGO_AUTO at d=64: N <= 256 keeps the interleaved kernels (256-row workgroups from two per CU upwards); longer
+    sequences take the rolling pipeline on the widest waves whose grid still covers the device (512 / 256 / 128-row
+    workgroups by rounds x rows / efficiency).  Shapes on each side of the switches, through algo 0, against the oracle."""
     torch = torch_cuda
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     L = fa.lib()
     big = 24
-    for (bh, n, want_algo) in [(cus - 1, 512, 6), (cus, 512, big), (2 * cus - 1, 256, 6), (2 * cus, 256, 5), (cus, 500, big), (cus // 2, 513, big), (4 * cus, 250, 5)]:
+    for (bh, n, want_algo) in [(cus - 1, 512, big), (cus, 512, big), (2 * cus - 1, 256, 6), (2 * cus, 256, 5), (cus, 500, big), (cus // 2, 513, big), (4 * cus, 250, 5),
+                               (cus // 8, 1024, 27), (cus // 4, 1024, 26), (cus // 8, 700, 27), (3 * cus // 2, 512, 26)]:
         sel = L.fa_selected_algo(bh, 1, n, 64, fmt)
         if want_algo is not None:
             assert sel == want_algo, (bh, n, sel)
@@ -655,7 +657,7 @@ def test_bf16_overflow_window_below_inf(fa, oracle, torch_cuda):
     q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
     qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
     want = oracle.forward(q, k, v, accum=1, nthreads=8)
-    for algo in (a for a in (0, 5, 6, 13, 16, 21, 23, 24, 14, 17) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 13, 16, 21, 23, 24, 26, 27, 14, 17) if a not in _EXPERIMENTAL or _have_exp()):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"bf16 window algo={algo}", max_abs=4 * MAX_ABS)   # |V| = 4 x the N(0,1) bar
 
@@ -704,7 +706,7 @@ def test_folded_pass_gates(fa, oracle, torch_cuda, fmt):
         q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
         qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
         want = oracle.forward(q, k, v, accum=1, nthreads=8, **({} if scale is None else {"scale": scale}))
-        for algo in (a for a in (24, 23, 22, 21, 0) if a not in _EXPERIMENTAL or _have_exp()):
+        for algo in (a for a in (24, 26, 27, 23, 22, 21, 0) if a not in _EXPERIMENTAL or _have_exp()):
             got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo, scale=scale)
             _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo} fmt={fmt}", max_abs=MAX_ABS * (1.0 if fmt == 0 else 2.5))
 
