@@ -95,6 +95,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
 }
+// per-lane offset + wave-uniform offset (SGPR): one address register serves many loads
+__device__ __forceinline__ u32x4 buf_load16_s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
 // explicit cache policy (gfx94x/gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1)
 template <int kAux>
 __device__ __forceinline__ u32x4 buf_load16_cp(__amdgpu_buffer_rsrc_t r, unsigned voff) {

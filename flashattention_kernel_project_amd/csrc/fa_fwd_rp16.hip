@@ -55,13 +55,20 @@ constexpr float kFoldAim = 6.0f;       // folded pass: log2 of the row sum the r
 constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores' maximum it may go (weights stay below 2^16)
 #ifndef FA_RP16_ABL
 #define FA_RP16_ABL 0              // lab only (timing ablations, results are garbage): 1 no LDS fragment reads, 2 no softmax vector
-#endif                             // work, 4 no matrix instructions, 8 no K/V staging, 16 no tile barrier
+#endif                             // work, 4 no matrix instructions, 8 no K/V staging, 16 no tile barrier, 32 no O stores, 64 no Q loads,
+                                   // 128 no loads of an item's first two K/V tiles
 #ifndef FA_RP16_GATES
 #define FA_RP16_GATES 15           // lab only: which refusal gates of the folded pass are armed (1 sum overflow, 2 sum too small, 4 reference, 8 Q range)
 #endif
 #ifndef FA_RP16_SUMMFMA
 #define FA_RP16_SUMMFMA 1          // 1: the optimistic passes take the row sums from the matrix pipe (one more PV block against a
 #endif                             // fragment of ones: X matrix instructions per step instead of 32 v_add_f32 per lane)
+#ifndef FA_RP16_PREFETCH
+#define FA_RP16_PREFETCH 1         // 1: the next item's Q rows are requested under this item's epilogue, ahead of its stores
+#endif
+#ifndef FA_RP16_PRIO
+#define FA_RP16_PRIO 0             // lab only: 1 = waves 0-3 (one of the two on each SIMD) run at raised priority
+#endif
 #ifndef FA_RP16_RUNSUM
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
@@ -165,28 +172,115 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         return v + __shfl_xor(v, 32, 64);
     };
 
+    if constexpr (FA_RP16_PRIO == 1) { if (wave < 4u) __builtin_amdgcn_s_setprio(2); }   // lab: one wave of each SIMD's pair ahead
     const unsigned nwg = total_wg;
-    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
-    if (bid != blockIdx.x) __syncthreads();
-    const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid & 7u;
-    const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const unsigned bh = wgid / (unsigned)nqb;
-    const unsigned qbi = wgid - bh * (unsigned)nqb;
-    unsigned qb = qbi;
-    if constexpr (kCausal) {
-        // Alternate the direction of the query blocks from one round of the persistent grid to the next, so that a CU's
-        // items add up to about the same number of tiles.  The direction must be a function of the HEAD alone (all its
-        // query blocks flip together, else two items would compute the same block): take the round of the head's first
-        // item, found through the inverse of the XCD remap above.
-        const unsigned t0 = bh * (unsigned)nqb, big = xr * (xq + 1u);
-        const unsigned x0 = t0 < big ? t0 / (xq + 1u) : xr + (t0 - big) / (xq ? xq : 1u);
-        const unsigned start0 = x0 < xr ? x0 * (xq + 1u) : big + (x0 - xr) * xq;
-        const unsigned bid0 = 8u * (t0 - start0) + x0;
-        if (((bid0 / gridDim.x) & 1u) == 0u) qb = (unsigned)nqb - 1u - qbi;
-    }
+    // work item -> (head, query block): XCD-aware remap of the persistent grid's item index
+    auto locate = [&](unsigned bid_, unsigned& bh_, unsigned& qb_) __attribute__((always_inline)) {
+        const unsigned xq = nwg >> 3, xr = nwg & 7u, xcd = bid_ & 7u;
+        const unsigned wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid_ >> 3);
+        bh_ = wgid / (unsigned)nqb;
+        const unsigned qbi = wgid - bh_ * (unsigned)nqb;
+        qb_ = qbi;
+        if constexpr (kCausal) {
+            // Alternate the direction of the query blocks from one round of the persistent grid to the next, so that a CU's
+            // items add up to about the same number of tiles.  The direction must be a function of the HEAD alone (all its
+            // query blocks flip together, else two items would compute the same block): take the round of the head's first
+            // item, found through the inverse of the XCD remap above.
+            const unsigned t0 = bh_ * (unsigned)nqb, big = xr * (xq + 1u);
+            const unsigned x0 = t0 < big ? t0 / (xq + 1u) : xr + (t0 - big) / (xq ? xq : 1u);
+            const unsigned start0 = x0 < xr ? x0 * (xq + 1u) : big + (x0 - xr) * xq;
+            const unsigned bid0 = 8u * (t0 - start0) + x0;
+            if (((bid0 / gridDim.x) & 1u) == 0u) qb_ = (unsigned)nqb - 1u - qbi;
+        }
+    };
     const size_t head_elems = (size_t)N * D;
     const unsigned head_bytes = (unsigned)(head_elems * 2);
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(Qg + bh * head_elems, head_bytes);
+    // Between two items of the persistent loop everything is a latency chain (stamps: Q 2.8-4.4 us, then K/V 2.2, reference
+    // 2.2, gates 1.8, stores 1.6 of ~116 us per item at B8 H16 N4096).  kPrefetch: the NEXT item's Q rows are requested
+    // (raw, into qf -- dead by then) as soon as the first pass' tile loop is over, i.e. ahead of this item's stores in the
+    // in-order vector memory queue, and every item requests its first three K/V tiles before it waits for its Q.
+    constexpr bool kPrefetch = FA_RP16_PREFETCH != 0 && !kDma;
+    constexpr bool kCarryKV = FA_RP16_PREFETCH == 2;   // lab: the K/V tiles 0..2 carried in registers as well (the allocator spills them)
+    u32x4 qf[X][kKS];   // B operand of QK^T: Q[row of block x][32 ks + 8 g .. +7]
+    u32x4 kst[kLoads], vst[kLoads];
+    u32x4 pfk[2][kLoads], pfv[2][kLoads];
+    // hb: the head's Q; row_base: the wave's first row (wave-uniform, folded into the descriptor: the bounds check -- rows past
+    // N read zeros -- covers the per-lane and the immediate offset only).  One per-lane address, recomputed here from the lane
+    // id so that nothing of it lives across the tile loop.
+    auto q_issue = [&](const uint16_t* hb, unsigned row_base) __attribute__((always_inline)) {
+        unsigned l = lane;
+        asm volatile("" : "+v"(l));
+        const unsigned voff = (l & 15u) * kRowB + (l >> 4) * 16u;
+        const unsigned rb = __builtin_amdgcn_readfirstlane(row_base);
+        const unsigned skip = rb * kRowB;
+        // (the pointer is wave-uniform by construction; saying so spares the descriptor a waterfall loop per load)
+        const unsigned long long pa = (unsigned long long)(hb + (size_t)rb * D);
+        const unsigned p_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);   // (the builtin returns int: no sign
+        const unsigned p_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));   // extension into the high half)
+        const unsigned long long pu = (unsigned long long)p_lo | ((unsigned long long)p_hi << 32);
+        const __amdgpu_buffer_rsrc_t rq_ = make_rsrc(reinterpret_cast<const uint16_t*>(pu),
+                                                     __builtin_amdgcn_readfirstlane(skip < head_bytes ? head_bytes - skip : 0u));
+#pragma unroll
+        for (int x = 0; x < X; ++x)
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                if constexpr ((FA_RP16_ABL & 64) != 0) qf[x][ks] = zero4u;
+                else qf[x][ks] = buf_load16(rq_, voff + ((16u * x) * kRowB + 64u * ks));
+            }
+    };
+    auto kv_issue = [&](__amdgpu_buffer_rsrc_t rk_, __amdgpu_buffer_rsrc_t rv_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < kLoads; ++p) {   // all loads of the three tiles in flight together
+            if constexpr ((FA_RP16_ABL & 128) != 0) {
+                pfk[0][p] = pfv[0][p] = pfk[1][p] = pfv[1][p] = kst[p] = vst[p] = zero4u;
+                continue;
+            }
+            pfk[0][p] = buf_load16(rk_, st_goff[p]);
+            pfv[0][p] = buf_load16(rv_, st_goff[p]);
+            pfk[1][p] = buf_load16(rk_, kTile + st_goff[p]);
+            pfv[1][p] = buf_load16(rv_, kTile + st_goff[p]);
+            kst[p] = buf_load16(rk_, 2u * kTile + st_goff[p]);
+            vst[p] = buf_load16(rv_, 2u * kTile + st_goff[p]);
+        }
+    };
+    constexpr unsigned kStores = (unsigned)(X * kDB);   // store instructions per item
+    if constexpr (kPrefetch) {
+        // The first item's inputs, requested the way every later item's are (at the end of the item before it, ahead of that
+        // item's stores) -- including kStores stores, so that both ways into the loop look alike to the wait-count
+        // bookkeeping (s_waitcnt vmcnt counts in order: with the same instructions behind the loads on both paths the waits
+        // for Q and K/V can leave exactly the stores outstanding).  The stand-in stores put one zero chunk per wave on the first
+        // row the wave will really store later (same wave, same address, program order: the real value wins).
+        if (blockIdx.x < nwg) {
+            unsigned bh0, qb0;
+            locate(blockIdx.x, bh0, qb0);
+            bh0 = __builtin_amdgcn_readfirstlane(bh0);
+            qb0 = __builtin_amdgcn_readfirstlane(qb0);
+            const unsigned rb0 = qb0 * kRows + wave * (16u * X);
+            q_issue(Qg + bh0 * head_elems, rb0);
+            if constexpr (kCarryKV) kv_issue(make_rsrc(Kg + bh0 * head_elems, head_bytes), make_rsrc(Vg + bh0 * head_elems, head_bytes));
+            constexpr unsigned es0 = kOutF32 ? 4u : 2u;
+            const __amdgpu_buffer_rsrc_t ro0 =
+                make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh0 * head_elems * es0, (unsigned)(head_elems * es0));
+#pragma unroll
+            for (unsigned i = 0; i < kStores; ++i) {
+                u32x4 z = zero4u;
+                asm volatile("" : "+v"(z));
+                if constexpr (kOutF32) buf_store16(ro0, rb0 * D * 4u, z);
+                else buf_store8(ro0, rb0 * D * 2u, u32x2{z[0], z[1]});
+            }
+        }
+    }
+    for (unsigned bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+#ifdef FA_RP16_STAMPS   // lab: 100 MHz timestamps of the item's phases, written over O[first row of the item][0..7] (fp32 out only)
+    unsigned long long ts[8] = {};
+#define FA_STAMP(i) ts[i] = wall_clock64()
+#else
+#define FA_STAMP(i)
+#endif
+    FA_STAMP(0);
+    if (bid != blockIdx.x) __syncthreads();
+    unsigned bh, qb;
+    locate(bid, bh, qb);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
     const unsigned q_row0 = qb * kRows + wave * (16u * X) + c16;   // row of block 0; block x is 16x rows further
@@ -194,16 +288,15 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const int nt = kCausal ? min(ntiles, (int)(min((unsigned)N - 1u, qb * kRows + kRows - 1u) / kBlockN) + 1) : ntiles;
     const int jc = kCausal ? (int)((qb * kRows) / kBlockN) : nt;
 
-    u32x4 qf[X][kKS];   // B operand of QK^T: Q[row of block x][32 ks + 8 g .. +7]
     int q_bad = 0;
-    auto load_q = [&](auto fold_c) __attribute__((always_inline)) {
+    auto q_finish = [&](auto fold_c) __attribute__((always_inline)) {   // raw rows in qf -> the B operands of this pass
         constexpr bool fold = decltype(fold_c)::value;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             float amax = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks) {
-                u32x4 raw = buf_load16(rq, (q_row0 + 16u * x) * kRowB + (32u * ks + 8u * g) * 2u);
+                u32x4 raw = qf[x][ks];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     if constexpr (fold) {
@@ -222,6 +315,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         // products alive (spilled) across it -- 33 MB of scratch written and read back per item
         if constexpr (fold) asm volatile("" : "+v"(q_bad));
     };
+    auto load_q = [&](auto fold_c) __attribute__((always_inline)) {
+        q_issue(Qg + bh * head_elems, q_row0 - c16);
+        q_finish(fold_c);
+    };
 
     // bf16 K chunk -> fp16 (folded pass of bf16 inputs); k_amax collects the largest magnitude this thread converted
     float k_amax = 0.0f;
@@ -239,14 +336,14 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     f32x4 o[X][kDB];
     float m_ref[X] = {}, l_part[X] = {};
     float ls[X][2];   // optimistic passes: two running row-sum chains per block, folded into l_part once per item
-    u32x4 kst[kLoads], vst[kLoads];
     u32x4 frag[kRing];
     f32x4 minit;   // folded pass: every score chain starts at -(wave reference maximum)
     // row sums on the matrix pipe: lacc[x][i] = sum over keys of the ROUNDED weights of row (lane & 15) of block x, the
     // same in every register and every lane group (all 16 "head-dim rows" of the ones fragment are equal)
     f32x4 lacc[X];
-    u32x4 ones = {T::kOnes2, T::kOnes2, T::kOnes2, T::kOnes2};
-    if constexpr (FA_RP16_SUMMFMA) asm volatile("" : "+v"(ones));   // stays in registers, not re-materialised per use
+    u32x4 ones;   // written by an instruction the optimiser cannot hoist out of the item loop (and spill around the tile loop)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(ones[i]) : "s"(T::kOnes2));
 
     // K fragment (key block kbl of half h in slot offset so, k-step ks); V^T fragment (head-dim block db) of half h
     auto read_kf = [&](unsigned so, int h, int kbl, int ks) -> u32x4 {
@@ -266,7 +363,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // odd f -> V^T fragment db = f/2 of the PV unit
     auto read_frag = [&](auto fc, unsigned so_q, int h_q, unsigned so_v, int h_v) {
         constexpr int f = decltype(fc)::value;
-        if constexpr ((FA_RP16_ABL & 1) != 0) return;
+        if constexpr ((FA_RP16_ABL & 1) != 0) {   // "defined" without an instruction, so that no consumer is folded away
+            asm volatile("" : "=v"(frag[f % kRing]));
+            return;
+        }
         if constexpr ((f & 1) == 0) frag[f % kRing] = read_kf(so_q, h_q, (f >> 1) / kKS, (f >> 1) % kKS);
         else frag[f % kRing] = read_vf(so_v, h_v, f >> 1);
     };
@@ -445,8 +545,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 
     // mode 0: folded fast pass; 1: exact, reference max fixed after the first 32 keys; 2: exact, lazy running max
     // returns true when the folded pass gave up right after its reference was known (nothing computed yet)
-    auto run = [&](auto mode_c) __attribute__((always_inline)) -> bool {
+    // pre_c: the item's first three K/V tiles are already in flight (requested at the end of the previous item)
+    auto run = [&](auto mode_c, auto pre_c) __attribute__((always_inline)) -> bool {
         constexpr int kMode = decltype(mode_c)::value;
+        constexpr bool kPre = decltype(pre_c)::value;
         constexpr bool kTrack = kMode == 2, kFast = kMode == 0;
         const std::integral_constant<bool, kFast> fast_c{};
         f32x4 sA[X][2], sB[X][2];
@@ -466,25 +568,19 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             for (int p = 0; p < kLoads; ++p) lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
             dma_tile(rk, rv, 0u, 0u);
             dma_tile(rk, rv, kTile, kSlotBytes);
-        } else {   // all loads of both tiles in flight together
-            u32x4 k1[kLoads], v1[kLoads];
-#pragma unroll
-            for (int p = 0; p < kLoads; ++p) {
-                kst[p] = buf_load16(rk, st_goff[p]);
-                vst[p] = buf_load16(rv, st_goff[p]);
-                k1[p] = buf_load16(rk, kTile + st_goff[p]);
-                v1[p] = buf_load16(rv, kTile + st_goff[p]);
-            }
+        } else {   // tiles 0 and 1 -> LDS; tile 2 stays in the staging registers until iteration 0 lands it
+            if constexpr (!kPre) kv_issue(rk, rv);
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
                 lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
-                lds_write16(smem, k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
-                lds_write16(smem, v_lds[p], vst[p]);
-                lds_write16(smem, kSlotBytes + k_lds[p], (kCvtK && kFast) ? k_to_f16(k1[p]) : k1[p]);
-                lds_write16(smem, kSlotBytes + v_lds[p], v1[p]);
+                lds_write16(smem, k_lds[p], (kCvtK && kFast) ? k_to_f16(pfk[0][p]) : pfk[0][p]);
+                lds_write16(smem, v_lds[p], pfv[0][p]);
+                lds_write16(smem, kSlotBytes + k_lds[p], (kCvtK && kFast) ? k_to_f16(pfk[1][p]) : pfk[1][p]);
+                lds_write16(smem, kSlotBytes + v_lds[p], pfv[1][p]);
             }
         }
         __syncthreads();
+        if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(2);
 #pragma unroll
         for (int kbl = 0; kbl < 2; ++kbl)   // S(unit 0)
 #pragma unroll
@@ -523,7 +619,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     e = across_sum(e);
 #pragma unroll
                     for (int off = 1; off < 16; off <<= 1) e += __shfl_xor(e, off, 64);
-                    const float shift = __builtin_amdgcn_logf((float)N * e * (1.0f / (16.0f * X * 32.0f))) - kFoldAim;
+                    // (N through an opaque copy: hoisted out of the item loop, the product would be spilled around the tile
+                    // loop and its reload -- s_waitcnt vmcnt(0) -- would sit behind whatever memory traffic is in flight)
+                    int n_here = N;
+                    asm volatile("" : "+s"(n_here));
+                    const float shift = __builtin_amdgcn_logf((float)n_here * e * (1.0f / (16.0f * X * 32.0f))) - kFoldAim;
                     mw += fminf(fmaxf(shift, -kFoldShiftMin), kFoldMax);
                 }
 #pragma unroll
@@ -548,11 +648,16 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             sfor<kAhead>([&](auto fc) { read_frag(fc, 0u, 1, 3u * kSlotBytes, 1); });
         }
 
-        auto tile_iter = [&](int j, auto masked_c) __attribute__((always_inline)) {
-            const unsigned so_m1 = ((unsigned)(j + 3) & 3u) * kSlotBytes, so_0 = ((unsigned)j & 3u) * kSlotBytes;
-            const unsigned so_p1 = ((unsigned)(j + 1) & 3u) * kSlotBytes, so_p2 = ((unsigned)(j + 2) & 3u) * kSlotBytes;
+        // phase_c: j & 3 when the caller knows it at compile time (the unrolled steady state: ring slot offsets become
+        // immediates of the LDS instructions instead of one v_add per fragment read), -1 otherwise
+        // req_c: request tile j+2 at the top (not in iteration 0 of the non-DMA path: the prologue already has it in flight)
+        auto tile_iter = [&](int j, auto masked_c, auto phase_c, auto req_c) __attribute__((always_inline)) {
+            constexpr int ph = decltype(phase_c)::value;
+            const unsigned jj = ph >= 0 ? (unsigned)ph : (unsigned)j;
+            const unsigned so_m1 = ((jj + 3u) & 3u) * kSlotBytes, so_0 = (jj & 3u) * kSlotBytes;
+            const unsigned so_p1 = ((jj + 1u) & 3u) * kSlotBytes, so_p2 = ((jj + 2u) & 3u) * kSlotBytes;
             // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
-            if constexpr ((FA_RP16_ABL & 8) != 0) {
+            if constexpr ((FA_RP16_ABL & 8) != 0 || !decltype(req_c)::value) {
             } else if constexpr (kDma) {
                 dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_p2);   // the barrier below waits for it (vmcnt) and publishes it
             } else {
@@ -573,20 +678,29 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             }
             if constexpr ((FA_RP16_ABL & 16) == 0) __syncthreads();
         };
+        if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(3);
+        using dyn = std::integral_constant<int, -1>;
+        const std::integral_constant<bool, kDma> req0{};   // iteration 0 only requests on the DMA path
+        auto full_tiles = [&](int nfull) __attribute__((always_inline)) {
+            int j = 0;
+            if (nfull > 0) { tile_iter(0, no, dyn{}, req0); j = 1; }
+            for (; j < nfull; ++j) tile_iter(j, no, dyn{}, yes);
+        };
+        // (a masked or tracked iteration 0 requests tile 2 once more: the same data into the same registers)
         if constexpr (kTrack) {
-            for (int j = 0; j < nt; ++j) tile_iter(j, no);
+            for (int j = 0; j < nt; ++j) tile_iter(j, no, dyn{}, yes);
         } else if constexpr (kCausal) {
-            for (int j = 0; j < jc; ++j) tile_iter(j, no);
-            for (int j = jc; j < nt; ++j) tile_iter(j, yes);
+            full_tiles(jc);
+            for (int j = jc; j < nt; ++j) tile_iter(j, yes, dyn{}, yes);
         } else {
-            const int nfull = partial ? ntiles - 1 : ntiles;
-            for (int j = 0; j < nfull; ++j) tile_iter(j, no);
-            if (partial) tile_iter(ntiles - 1, yes);
+            full_tiles(partial ? ntiles - 1 : ntiles);
+            if (partial) tile_iter(ntiles - 1, yes, dyn{}, yes);
         }
         if constexpr (!kTrack && FA_RP16_RUNSUM && !FA_RP16_SUMMFMA) {
 #pragma unroll
             for (int x = 0; x < X; ++x) l_part[x] = ls[x][0] + ls[x][1];
         }
+        if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(4);
         // ---- epilogue: O^T += V(last tile, half 1)^T.P^T ----
         {
             const unsigned so = ((unsigned)(nt - 1) & 3u) * kSlotBytes;
@@ -610,19 +724,39 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     float l_row[X];
     const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
     bool bad = false;
+    if constexpr (!kPrefetch) q_issue(Qg + bh * head_elems, q_row0 - c16);   // else: requested by the item before (next_in)
+    else if constexpr (!kCarryKV) kv_issue(rk, rv);   // tiles 0..2 on their way before Q is waited for
+    const std::integral_constant<bool, kPrefetch> pre_c{};
+    // qf, pfk/pfv, kst/vst <- the next item's raw Q rows and K/V tiles 0..2 (called between the last pass and the stores)
+    auto next_in = [&]() __attribute__((always_inline)) {
+        if constexpr (kPrefetch) {
+            const unsigned nbid = bid + gridDim.x;
+            if (nbid < nwg) {
+                unsigned bh_n, qb_n;
+                locate(nbid, bh_n, qb_n);
+                bh_n = __builtin_amdgcn_readfirstlane(bh_n);   // (uniform anyway: spares the descriptors a waterfall loop)
+                qb_n = __builtin_amdgcn_readfirstlane(qb_n);
+                q_issue(Qg + bh_n * head_elems, qb_n * kRows + wave * (16u * X));
+                if constexpr (kCarryKV) kv_issue(make_rsrc(Kg + bh_n * head_elems, head_bytes), make_rsrc(Vg + bh_n * head_elems, head_bytes));
+            }
+        }
+    };
     if constexpr (kFold) {
         k_amax = 0.0f;
-        load_q(yes);
-        const bool gave_up = run(std::integral_constant<int, 0>{});
+        q_finish(yes);
+        FA_STAMP(1);
+        const bool gave_up = run(std::integral_constant<int, 0>{}, pre_c);
         // fp16 weights: each subnormal one is off by at most 2^-25, N of them by N * 2^-25 in the worst case (2^-13 * sqrt(N)
         // typically), which stays below 2^-9 of the row sum; bf16 weights only must not vanish in fp32 (a row more than ~100
         // log2 units below its wave's reference: p = 0, l = 0)
-        const float lo = T::id == 0 ? (float)N * 0x1p-16f : 0x1p-100f;
+        int n_here = N;
+        asm volatile("" : "+s"(n_here));   // as above: no spilled constant behind the Q prefetch
+        const float lo = T::id == 0 ? (float)n_here * 0x1p-16f : 0x1p-100f;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             l_row[x] = across_sum(l_part[x]);
             // causal: a row only has row+1 keys to add up
-            const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)N, q_row0 + 16u * x + 1u) * 0x1p-16f : lo;
+            const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)n_here, q_row0 + 16u * x + 1u) * 0x1p-16f : lo;
             bad = bad || ((FA_RP16_GATES & 1) && !(l_row[x] < lim)) || ((FA_RP16_GATES & 2) && !(l_row[x] >= lo_x)) ||
                   ((FA_RP16_GATES & 4) && !(fabsf(m_ref[x]) <= kFoldMax));
         }
@@ -632,7 +766,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         // it is what large logits need; bf16 weights cannot overflow in it), the tracked pass only if that overflows too
         if (__syncthreads_or(bad ? 1 : 0)) {
             load_q(no);
-            run(std::integral_constant<int, 1>{});
+            run(std::integral_constant<int, 1>{}, no);
             bad = false;
 #pragma unroll
             for (int x = 0; x < X; ++x) {
@@ -643,8 +777,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             bad = false;
         }
     } else {
-        load_q(no);
-        run(std::integral_constant<int, 1>{});
+        q_finish(no);
+        run(std::integral_constant<int, 1>{}, pre_c);
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             l_row[x] = across_sum(l_part[x]);
@@ -652,34 +786,61 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
-        run(std::integral_constant<int, 2>{});
+        run(std::integral_constant<int, 2>{}, no);
 #pragma unroll
         for (int x = 0; x < X; ++x) l_row[x] = across_sum(l_part[x]);
     }
-
+    // normalise in place FIRST (no temporaries alive when the prefetch takes its registers), then the next item's loads, then
+    // the stores straight from the accumulators
+#pragma unroll
+    for (int x = 0; x < X; ++x) {
+        const float inv = 1.0f / l_row[x];
+#pragma unroll
+        for (int db = 0; db < kDB; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[x][db][i] *= inv;
+#ifdef FA_RP16_DIAG
+        if (g == 0) { o[x][0][0] = l_row[x]; o[x][0][1] = m_ref[x]; }
+#endif
+    }
+    FA_STAMP(5);
+    if constexpr (kPrefetch) {
+#pragma unroll
+        for (int x = 0; x < X; ++x)
+#pragma unroll
+            for (int db = 0; db < kDB; ++db) asm volatile("" : "+v"(o[x][db]));   // the multiplies stay in front of the loads
+    }
+    next_in();
     // o[x][db][i] = O[q_row0 + 16x][16 db + 4 g + i]
     constexpr unsigned es = kOutF32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t ro =
         make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh * head_elems * es, (unsigned)(head_elems * es));
 #pragma unroll
     for (int x = 0; x < X; ++x) {
-        const float inv = 1.0f / l_row[x];
         const unsigned row = q_row0 + 16u * x;
 #pragma unroll
         for (int db = 0; db < kDB; ++db) {
             const unsigned col = 16u * db + 4u * g;
-            float a = o[x][db][0] * inv, b = o[x][db][1] * inv, cc = o[x][db][2] * inv, d = o[x][db][3] * inv;
-#ifdef FA_RP16_DIAG
-            if (db == 0 && g == 0) { a = l_row[x]; b = m_ref[x]; }
-#endif
             if constexpr (kOutF32) {
-                const f32x4 v = {a, b, cc, d};
-                buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, v));
+                if constexpr ((FA_RP16_ABL & 32) != 0) asm volatile("" :: "v"(o[x][db]));
+                else buf_store16(ro, (row * D + col) * 4u, __builtin_bit_cast(u32x4, o[x][db]));
             } else {
-                buf_store8(ro, (row * D + col) * 2u, u32x2{T::pack2(a, b), T::pack2(cc, d)});
+                buf_store8(ro, (row * D + col) * 2u, u32x2{T::pack2(o[x][db][0], o[x][db][1]), T::pack2(o[x][db][2], o[x][db][3])});
             }
         }
     }
+#ifdef FA_RP16_STAMPS
+    FA_STAMP(6);
+    if constexpr (kOutF32) {
+        if (tid == 0) {
+            float* orow = reinterpret_cast<float*>(Og) + ((size_t)bh * N + (size_t)qb * kRows) * D;
+            orow[0] = (float)(ts[0] & 0xFFFFFFull);
+            for (int i = 1; i < 7; ++i) orow[i] = (float)(long long)(ts[i] - ts[0]);
+            orow[7] = (float)blockIdx.x;
+        }
+    }
+#endif
+#undef FA_STAMP
     }   // persistent loop over work items
 }
 
