@@ -163,6 +163,19 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const std::false_type no{};
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
+    // v of the lane `sh` places further round the lane's row of 16 (DPP row_ror: no LDS round trip like ds_bpermute); four
+    // doubling steps (1, 2, 4, 8) leave the row's maximum / sum in every lane
+    auto row_ror = [&](float v, int sh) -> float {
+        const int iv = __builtin_bit_cast(int, v);
+        int r;
+        switch (sh) {
+            case 1: r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xF, 0xF, true); break;
+            case 2: r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xF, 0xF, true); break;
+            case 4: r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xF, 0xF, true); break;
+            default: r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, true); break;
+        }
+        return __builtin_bit_cast(float, r);
+    };
     auto across_max = [&](float v) -> float {   // over the four lanes that share a query row
         v = fmaxf(v, __shfl_xor(v, 16, 64));
         return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -601,7 +614,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
                 for (int x = 0; x < X; ++x) mw = fmaxf(mw, row_max(s0[x]));
 #pragma unroll
-                for (int off = 1; off < 16; off <<= 1) mw = fmaxf(mw, __shfl_xor(mw, off, 64));
+                for (int sh = 1; sh < 16; sh <<= 1) mw = fmaxf(mw, row_ror(mw, sh));   // over the 16 rows of a lane group (DPP)
                 if (kCausal || (partial && ntiles == 1)) {
                     mw += kHeadroomFold;
                 } else {
@@ -618,7 +631,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                             for (int i = 0; i < 4; ++i) e += fast_exp2(s0[x][kbl][i] - mw);
                     e = across_sum(e);
 #pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) e += __shfl_xor(e, off, 64);
+                    for (int sh = 1; sh < 16; sh <<= 1) e += row_ror(e, sh);
                     // (N through an opaque copy: hoisted out of the item loop, the product would be spilled around the tile
                     // loop and its reload -- s_waitcnt vmcnt(0) -- would sit behind whatever memory traffic is in flight)
                     int n_here = N;
@@ -714,7 +727,6 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
                 for (int x = 0; x < X; ++x) {
                     lacc[x] = M::mfma(ones, pkB[x], lacc[x]);
-                    l_part[x] = lacc[x][0] * 0.25f;   // across_sum adds the four lane groups' (equal) copies
                 }
             }
         }
@@ -723,7 +735,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 
     float l_row[X];
     const float lim = T::id == 1 ? 0x1p+96f : 60000.0f;
-    bool bad = false;
+    bool bad = false, second_vote = false;
+    // an optimistic pass' row sum: complete in every lane when it came from the matrix pipe
+    auto row_sum = [&](int x) -> float { return FA_RP16_SUMMFMA ? lacc[x][0] : across_sum(l_part[x]); };
     if constexpr (!kPrefetch) q_issue(Qg + bh * head_elems, q_row0 - c16);   // else: requested by the item before (next_in)
     else if constexpr (!kCarryKV) kv_issue(rk, rv);   // tiles 0..2 on their way before Q is waited for
     const std::integral_constant<bool, kPrefetch> pre_c{};
@@ -754,7 +768,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         const float lo = T::id == 0 ? (float)n_here * 0x1p-16f : 0x1p-100f;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
-            l_row[x] = across_sum(l_part[x]);
+            l_row[x] = row_sum(x);
             // causal: a row only has row+1 keys to add up
             const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)n_here, q_row0 + 16u * x + 1u) * 0x1p-16f : lo;
             bad = bad || ((FA_RP16_GATES & 1) && !(l_row[x] < lim)) || ((FA_RP16_GATES & 2) && !(l_row[x] >= lo_x)) ||
@@ -770,26 +784,27 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             bad = false;
 #pragma unroll
             for (int x = 0; x < X; ++x) {
-                l_row[x] = across_sum(l_part[x]);
+                l_row[x] = row_sum(x);
                 bad = bad || !(l_row[x] < lim);
             }
-        } else {
-            bad = false;
+            second_vote = true;
         }
     } else {
         q_finish(no);
         run(std::integral_constant<int, 1>{}, pre_c);
 #pragma unroll
         for (int x = 0; x < X; ++x) {
-            l_row[x] = across_sum(l_part[x]);
+            l_row[x] = row_sum(x);
             bad = bad || !(l_row[x] < lim);
         }
+        second_vote = true;
     }
-    if (__syncthreads_or(bad ? 1 : 0)) {
+    if (second_vote && __syncthreads_or(bad ? 1 : 0)) {   // (second_vote is uniform: the folded pass' own vote decided it)
         run(std::integral_constant<int, 2>{}, no);
 #pragma unroll
         for (int x = 0; x < X; ++x) l_row[x] = across_sum(l_part[x]);
     }
+
     // normalise in place FIRST (no temporaries alive when the prefetch takes its registers), then the next item's loads, then
     // the stores straight from the accumulators
 #pragma unroll
