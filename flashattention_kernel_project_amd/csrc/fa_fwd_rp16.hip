@@ -66,6 +66,9 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #ifndef FA_RP16_PREFETCH
 #define FA_RP16_PREFETCH 1         // 1: the next item's Q rows are requested under this item's epilogue, ahead of its stores
 #endif
+#ifndef FA_RP16_STAGGER
+#define FA_RP16_STAGGER 0          // lab: workgroups start in 8 phases, this many s_sleep units (~64 clocks each) apart, so that the
+#endif                             // item boundaries (stores, next Q) of the CUs do not all hit the memory system together
 #ifndef FA_RP16_PRIO
 #define FA_RP16_PRIO 0             // lab only: 1 = waves 0-3 (one of the two on each SIMD) run at raised priority
 #endif
@@ -185,6 +188,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         return v + __shfl_xor(v, 32, 64);
     };
 
+    if constexpr (FA_RP16_STAGGER > 0) {
+        const unsigned phase = (blockIdx.x >> 3) & 7u;
+        for (unsigned i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(FA_RP16_STAGGER);
+    }
     if constexpr (FA_RP16_PRIO == 1) { if (wave < 4u) __builtin_amdgcn_s_setprio(2); }   // lab: one wave of each SIMD's pair ahead
     const unsigned nwg = total_wg;
     // work item -> (head, query block): XCD-aware remap of the persistent grid's item index
