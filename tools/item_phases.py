@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Where an item of the persistent pipeline spends its time outside the tile loop: in-kernel 100 MHz stamps of a
+-DFA_RP16_STAMPS build (tools/build_variant.sh stfin "-DFA_RP16_STAMPS"; the stamps overwrite O[first row of the
+item][0..7], so such a build is for this tool only).  B8 H16 N4096 d64 fp16, mean over the 256 items of each round.
+    python tools/item_phases.py stnopf stfin      (names of gpurun_variants/lib_<name>.so)"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from flashattention_kernel_project_amd import capi  # noqa: E402
+
+capi._share_torch_hip_runtime()
+B, H, N, d = 8, 16, 4096, 64
+g = torch.Generator(device="cuda").manual_seed(0)
+q, k, v = (torch.randn(B, H, N, d, generator=g, device="cuda").half() for _ in range(3))
+o = torch.empty(B, H, N, d, device="cuda", dtype=torch.float32)
+st = torch.cuda.current_stream().cuda_stream
+names = ["Q ready", "K/V tiles in LDS", "reference done", "tile loop done", "gates done", "stores issued"]
+print("# us since the item's start (mean over the items of a round of the persistent grid); 'item start' = us since the launch's first item")
+for name in sys.argv[1:]:
+    L = C.CDLL(os.path.join(ROOT, "gpurun_variants", f"lib_{name}.so"))
+    L.fa_forward_ex.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3 + [C.c_void_p]
+    for _ in range(200):
+        rc = L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, N, d, 0.125, 0, 0, 24, st)
+        assert rc == 0
+    torch.cuda.synchronize()
+    s = o.view(B * H, N // 512, 512, d)[:, :, 0, :8].reshape(-1, 8).cpu()   # one row of stamps per item
+    t0 = s[:, 0]
+    start = ((t0 - t0.min()) % (1 << 24)) / 100.0
+    order = torch.argsort(start)
+    s, start = s[order], start[order]
+    for r in range(4):
+        seg, beg = s[r * 256:(r + 1) * 256], start[r * 256:(r + 1) * 256]
+        print(f"{name:8s} round {r}: item start {float(beg.mean()):7.1f} (+-{float(beg.std()):.1f})  " +
+              "  ".join(f"{n} {float(seg[:, i + 1].mean()) / 100:.2f}" for i, n in enumerate(names)), flush=True)
