@@ -50,7 +50,7 @@ constexpr int kW = 8;
 constexpr int kAheadWide = FA_RP16_AHEAD;   // 64-row waves: fragments read ahead of their MFMAs (at most ring - 1), ring of 4 registers
 constexpr float kHeadroom = 4.0f;      // exact optimistic pass: reference = the row's max over its first 32 keys + this
 constexpr float kHeadroomFold = 1.0f;  // folded pass: the reference already is the maximum over the wave's 64 rows
-constexpr float kFoldMax = 24.0f;  // as fa_fwd_rp.hip
+constexpr float kFoldMax = 16.0f;  // folded pass: largest |reference| (log2 units) it accepts -- Q's fp16 rounding moves a logit by <= |logit| * 2^-11
 constexpr float kFoldAim = 6.0f;       // folded pass: log2 of the row sum the reference is placed for
 constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores' maximum it may go (weights stay below 2^16)
 #ifndef FA_RP16_ABL
