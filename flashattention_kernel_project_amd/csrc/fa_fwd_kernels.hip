@@ -523,11 +523,11 @@ int auto_algo(int BH, int N, int D, int in_dtype)
         return nwg256 >= 2 * cus ? 5 : 6;
     }
     // The rolling pipeline on the widest waves whose grid still covers the device: rounds of the persistent grid x rows per
-    // workgroup / efficiency of that width (LDS fragment reuse: 1.0 / 0.9 / 0.7 for 64- / 32- / 16-row waves; measured on
+    // workgroup / efficiency of that width (LDS fragment reuse: 1.0 / 0.9 / 0.7 for 64- / 32- / 16-row waves at d=64; measured on
     // B*H x N sweeps, tools/mid_grid_sweep.py -> profiles/r02_mid_grid.txt)
     const int wide = D == 64 ? 512 : 256;
     const int ids[3] = {24, 26, 27};
-    const double eff[3] = {1.0, 0.9, 0.7};
+    const double eff[3] = {1.0, D == 64 ? 0.9 : 0.72, 0.7};   // (d=128's half width is the 16-row wave)
     int best = 24;
     double best_cost = 0.0;
     for (int w = 0; w < (D == 64 ? 3 : 2); ++w) {

@@ -13,17 +13,22 @@ import flashattention_kernel_project_amd as fa  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="f16")
-ap.add_argument("--algos", default="0,5,6,24,26,27")
+ap.add_argument("--algos", default="")
+ap.add_argument("--d", type=int, default=64)
 args = ap.parse_args()
 dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
-algos = [int(a) for a in args.algos.split(",")]
+d = args.d
+algos = [int(a) for a in (args.algos or ("0,5,6,24,26,27" if d == 64 else "0,24,26")).split(",")]
 shapes = [(32, 1024), (8, 1024), (16, 2048), (64, 1024), (128, 512), (64, 512), (256, 256), (16, 4096), (32, 4096), (48, 4096),
           (8, 8192), (24, 2048), (96, 1024), (128, 1024), (40, 1536), (128, 300)]
+if d == 128:
+    shapes = [(32, 1024), (8, 1024), (16, 2048), (64, 1024), (128, 512), (64, 512), (16, 4096), (32, 4096), (48, 2048), (8, 8192), (24, 2048),
+              (96, 1024), (128, 1024), (40, 1536), (128, 300), (300, 300), (256, 256)]
 g = torch.Generator(device="cuda").manual_seed(0)
-print(f"# us per launch, {args.dtype}, d=64; algos {algos}; AUTO picks fa_selected_algo")
+print(f"# us per launch, {args.dtype}, d={d}; algos {algos}; AUTO picks fa_selected_algo")
 for BH, N in shapes:
-    q, k, v = (torch.randn(1, BH, N, 64, generator=g, device="cuda").to(dt) for _ in range(3))
-    o = torch.empty(1, BH, N, 64, device="cuda", dtype=torch.float32)
+    q, k, v = (torch.randn(1, BH, N, d, generator=g, device="cuda").to(dt) for _ in range(3))
+    o = torch.empty(1, BH, N, d, device="cuda", dtype=torch.float32)
     ref = None
     row = []
     for a in algos:
@@ -43,6 +48,6 @@ for BH, N in shapes:
         err = float((o - ref).abs().max())
         assert err < 5e-3, (BH, N, a, err)
         row.append(f"{a}:{statistics.median(ts):7.1f}")
-    sel = fa.lib().fa_selected_algo(1, BH, N, 64, 0 if args.dtype == "f16" else 1)
-    tf = 4.0 * BH * N * N * 64 / 1e6
+    sel = fa.lib().fa_selected_algo(1, BH, N, d, 0 if args.dtype == "f16" else 1)
+    tf = 4.0 * BH * N * N * d / 1e6
     print(f"BH {BH:4d} N {N:5d}  auto={sel:2d}  " + "  ".join(row) + f"   ({tf / min(float(r.split(':')[1]) for r in row):6.1f} TF best)", flush=True)
