@@ -729,6 +729,30 @@ def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda, fmt):
     _sampled_rows_check(fa, oracle, torch, q, k, v, a, fmt, [(0, 0, 0, 32), (1, 15, 4064, 32), (1, 7, 2000, 16)], "folded pass")
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_folded_pass_spread_inputs_all_widths(fa, oracle, torch_cuda, fmt):
+    """Q and K spread x1.5 / x2 / x3 (logits x2.25 / x4 / x9): where the wave reference is placed, the gates and the
+    fallback chain (folded -> exact optimistic -> tracked) decide the path per workgroup; every width of the pipeline
+    (algos 24, 26, 27; d=128: 24, 26) against the oracle on sampled rows and against the exact kernel on all rows."""
+    torch = torch_cuda
+    dt = _tdtype(torch, fmt)
+    for d, algos in ((64, (24, 26, 27)), (128, (24, 26))):
+        for spread in (1.5, 2.0, 3.0):
+            g = torch.Generator(device="cuda").manual_seed(int(100 * spread) + d + fmt)
+            q, k, v = (torch.randn(2, 3, 1100, d, generator=g, device="cuda") for _ in range(3))
+            q, k, v = (q * spread).to(dt), (k * spread).to(dt), v.to(dt)
+            exact = fa.fa_forward(q, k, v, algo=23)
+            for algo in algos:
+                o = fa.fa_forward(q, k, v, algo=algo)
+                torch.cuda.synchronize()
+                assert bool(torch.isfinite(o).all()), (d, spread, algo)
+                # peaked rows: a 16-bit weight moves O by 2^-11 (2^-8) of the spread of the dominant V rows
+                assert float((o - exact).abs().max()) <= (4e-3 if fmt == 0 else 3e-2), (d, spread, algo)
+                if fmt == 0:
+                    _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, [(0, 0, 0, 16), (1, 2, 1084, 16), (1, 1, 500, 8)],
+                                        f"spread {spread} d={d} algo={algo}")
+
+
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 path on ONE device: two ranks started by torch.distributed.run, gloo for the barrier and the
     max-reduction (the driver's own runs use RCCL), exactly one JSON line with n_gpus = 2."""
