@@ -66,6 +66,9 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #ifndef FA_RP16_PREFETCH
 #define FA_RP16_PREFETCH 1         // 1: the next item's Q rows are requested under this item's epilogue, ahead of its stores
 #endif
+#ifndef FA_RP16_TOP_BARRIER
+#define FA_RP16_TOP_BARRIER 0      // lab: 1 = a barrier at the top of every item but the first (what the votes make redundant)
+#endif
 #ifndef FA_RP16_STAGGER
 #define FA_RP16_STAGGER 0          // lab: workgroups start in 8 phases, this many s_sleep units (~64 clocks each) apart, so that the
 #endif                             // item boundaries (stores, next Q) of the CUs do not all hit the memory system together
@@ -298,7 +301,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #define FA_STAMP(i)
 #endif
     FA_STAMP(0);
-    if (bid != blockIdx.x) __syncthreads();
+    // No barrier here: the ring is only written again after the item's prologue loads have arrived, and every wave's last
+    // LDS read of the previous item (the epilogue's V fragments) lies before that item's vote (__syncthreads_or) -- or the
+    // barrier behind the tracked pass, which has no vote after it.  A wave therefore requests its K/V tiles as soon as its
+    // own stores are issued, not when the slowest wave's are.
+    if constexpr (FA_RP16_TOP_BARRIER) { if (bid != blockIdx.x) __syncthreads(); }
     unsigned bh, qb;
     locate(bid, bh, qb);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
@@ -810,6 +817,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         run(std::integral_constant<int, 2>{}, no);
 #pragma unroll
         for (int x = 0; x < X; ++x) l_row[x] = across_sum(l_part[x]);
+        __syncthreads();   // the next item's prologue writes the ring: every wave is past this pass' last LDS read
     }
 
     // normalise in place FIRST (no temporaries alive when the prefetch takes its registers), then the next item's loads, then
