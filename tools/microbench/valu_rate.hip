@@ -60,6 +60,14 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, i
 #define X(i) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(y[i & 7]) : "v"(x[i]), "v"(x[(i + 1) & 15]));
             REP16(X) REP16(X)
 #undef X
+        } else if constexpr (KIND == 27) {  // v_cvt_pkrtz_f16_f32 (round toward zero: the pre-gfx950 pack)
+#define X(i) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(y[i & 7]) : "v"(x[i]), "v"(x[(i + 1) & 15]));
+            REP16(X) REP16(X)
+#undef X
+        } else if constexpr (KIND == 28) {  // v_pack_b32_f16 of two fp16 halves
+#define X(i) asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(y[i & 7]) : "v"(x[i]), "v"(x[(i + 1) & 15]));
+            REP16(X) REP16(X)
+#undef X
         } else if constexpr (KIND == 6) {   // v_add_f32 fully independent destinations
 #define X(i) asm volatile("v_add_f32 %0, %1, %2" : "=v"(x[i]) : "v"(a), "v"(b));
             REP16(X) REP16(X)
@@ -206,6 +214,8 @@ int main()
     run<3>("v_add_f32 (4 chains)", 32);
     run<4>("v_max3_f32 (4 chains)", 32);
     run<5>("v_cvt_pk_f16_f32", 32);
+    run<27>("v_cvt_pkrtz_f16_f32", 32);
+    run<28>("v_pack_b32_f16", 32);
     run<6>("v_add_f32 (independent)", 32);
     run<7>("v_mul_f32", 32);
     run<8>("mix: 2 fma + 2 exp + 1 cvt (per 5 instr)", 80);
