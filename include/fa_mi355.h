@@ -30,8 +30,9 @@ extern "C" {
 #define FA_OUT_SAME   1   /* output in the input's 16-bit type */
 
 /* Kernel selection for fa_forward_ex().  Ids present in the product library: */
-#define FA_ALGO_AUTO            0 /* d=64: RP16_FOLD (INTERLEAVED / _2WG when N <= 256 or the grid is smaller than one
-                                     512-row workgroup per CU); d=128: RP16_FOLD; else GENERIC -- fa_selected_algo() */
+#define FA_ALGO_AUTO            0 /* d=64, N > 256 and d=128: RP16_FOLD on the widest waves whose grid still covers the device
+                                     (24, else _HALF 26, else _QUARTER 27, by rounds x rows / efficiency); d=64, N <= 256:
+                                     INTERLEAVED / _2WG; else GENERIC -- fa_selected_algo() */
 #define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
 #define FA_ALGO_INTERLEAVED     5 /* QK^T one tile ahead, PV one tile behind, one MFMA per slice of softmax VALU, D = 64 */
@@ -39,8 +40,8 @@ extern "C" {
 #define FA_ALGO_RP16           23 /* rolling half-tile pipeline on v_mfma_f32_16x16x32 (four 16-row blocks per wave at D = 64, two at D = 128),
                                      branch-free steady state, single-instruction fp32 vector work, exact passes */
 #define FA_ALGO_RP16_FOLD      24 /* RP16 with the folded fast pass: scale folded into a rounded Q, the wave's reference max as the
-                                     accumulators' start value (bf16: K converted to fp16 while it is staged); exact tracked pass
-                                     as the per-workgroup fallback */
+                                     accumulators' start value (bf16: K converted to fp16 while it is staged), row sums on the matrix
+                                     pipe; per-workgroup fallback chain: exact optimistic pass, then the tracked pass */
 #define FA_ALGO_RP16_FOLD_HALF 26 /* RP16_FOLD on half-width waves (256-row workgroups at D = 64, 128-row at D = 128): grids too
                                      small to cover the device with the full-width ones */
 #define FA_ALGO_RP16_FOLD_QUARTER 27 /* ... on quarter-width waves (128-row workgroups), D = 64 */
