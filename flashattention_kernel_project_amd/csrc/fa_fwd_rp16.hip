@@ -79,7 +79,7 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
 #ifndef FA_RP16_STAGE_SLOT
-#define FA_RP16_STAGE_SLOT 16      // matrix slot (of 32; scaled for narrower steps) of the second step in front of which tile j+2 is written to LDS
+#define FA_RP16_STAGE_SLOT 8       // matrix slot (of 32; scaled for narrower steps) of the second step in front of which tile j+2 is written to LDS
 #endif
 }  // namespace rp16
 
