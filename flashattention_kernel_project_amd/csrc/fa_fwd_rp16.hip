@@ -66,6 +66,12 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #ifndef FA_RP16_PREFETCH
 #define FA_RP16_PREFETCH 1         // 1: the next item's Q rows are requested under this item's epilogue, ahead of its stores
 #endif
+#ifndef FA_RP16_VALU_AT
+#define FA_RP16_VALU_AT 0          // lab: a vector pair-step goes behind the last (0) or the first (1) matrix instruction of its group
+#endif
+#ifndef FA_RP16_ONES_POS
+#define FA_RP16_ONES_POS 0         // lab: where in a step the X row-sum matrix instructions go: 0 one per kNF slots, 1 behind the first X
+#endif                             // slots, 2 behind the last X
 #ifndef FA_RP16_TOP_BARRIER
 #define FA_RP16_TOP_BARRIER 0      // lab: 1 = a barrier at the top of every item but the first (what the votes make redundant)
 #endif
@@ -494,15 +500,18 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 }
             }
             issue_mfma(ic);
-            if constexpr (FA_RP16_SUMMFMA && (FA_RP16_ABL & 4) == 0 && i % kNF == kNF - 1)
-                lacc[i / kNF] = M::mfma(ones, pk_prev[i / kNF], lacc[i / kNF]);
+            if constexpr (FA_RP16_SUMMFMA && (FA_RP16_ABL & 4) == 0) {   // the X row-sum instructions of the step
+                if constexpr (FA_RP16_ONES_POS == 0 && i % kNF == kNF - 1) lacc[i / kNF] = M::mfma(ones, pk_prev[i / kNF], lacc[i / kNF]);
+                if constexpr (FA_RP16_ONES_POS == 1 && i < X) lacc[i] = M::mfma(ones, pk_prev[i], lacc[i]);
+                if constexpr (FA_RP16_ONES_POS == 2 && i >= kSlots - X) lacc[i - (kSlots - X)] = M::mfma(ones, pk_prev[i - (kSlots - X)], lacc[i - (kSlots - X)]);
+            }
             if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
                 constexpr int f = i / X + kAhead;
                 if constexpr (f < kNF) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
                 else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
             }
             constexpr int kPer = kSlots / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
-            if constexpr (i % kPer == kPer - 1) valu_step(std::integral_constant<int, i / kPer>{});
+            if constexpr (i % kPer == (FA_RP16_VALU_AT ? 0 : kPer - 1)) valu_step(std::integral_constant<int, i / kPer>{});
         });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!FA_RP16_RUNSUM) {
