@@ -11,8 +11,8 @@ CSRC = os.path.join(_HERE, "csrc")
 
 F16, BF16 = 0, 1
 OUT_F32, OUT_SAME = 0, 1
-ALGO_AUTO, ALGO_GENERIC, ALGO_TILED, ALGO_PIPE, ALGO_PINGPONG, ALGO_INTERLEAVED, ALGO_INTERLEAVED_2WG = 0, 1, 2, 3, 4, 5, 6
-ALGO_TLP3, ALGO_IL16, ALGO_IL2X16, ALGO_W64, ALGO_W64P, ALGO_W64M, ALGO_W64X = 9, 11, 12, 13, 14, 15, 16
+ALGO_AUTO, ALGO_GENERIC, ALGO_TILED, ALGO_INTERLEAVED, ALGO_INTERLEAVED_2WG = 0, 1, 2, 5, 6
+ALGO_W64, ALGO_W64P, ALGO_W64X = 13, 14, 16
 ALGO_SK, ALGO_RP, ALGO_RP_FOLD, ALGO_RP16, ALGO_RP16_FOLD = 17, 21, 22, 23, 24
 ALGO_RP16_FOLD_HALF, ALGO_RP16_FOLD_QUARTER = 26, 27
 

@@ -20,8 +20,6 @@ hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, flo
 int auto_algo(int BH, int N, int D, int in_dtype);
 const char* algo_kernel_name(int algo, int D);
 #ifdef FA_EXPERIMENTS
-hipError_t pp_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
-                            int BH, int N, float scale, unsigned long long* diag, int mode, hipStream_t stream);
 hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O,
                             int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream);
 hipError_t sk_diag_dispatch(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale, int variant,
@@ -60,12 +58,6 @@ FA_EXPORT int fa_debug_il_times(const void* Q, const void* K, const void* V, voi
     return (int)fa::il_diag_dispatch(Q, K, V, O, BH, N, scale, diag, waves, static_cast<hipStream_t>(stream));
 }
 
-// phase-time stamps of the ping-pong kernel.
-FA_EXPORT int fa_debug_pp_phase_times(const void* Q, const void* K, const void* V, void* O,
-                            int BH, int N, float scale, unsigned long long* diag, int mode, void* stream)
-{
-    return (int)fa::pp_diag_dispatch(Q, K, V, O, BH, N, scale, diag, mode, static_cast<hipStream_t>(stream));
-}
 #endif  // FA_EXPERIMENTS
 
 // 1 when this build carries the experimental A/B kernels (explicit algo ids 3, 4, 7-12, 14, 15), else 0.

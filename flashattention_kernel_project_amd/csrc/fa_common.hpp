@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <tuple>
+#include <utility>
 
 namespace fa {
 
@@ -168,12 +170,23 @@ static inline int device_cus() {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus > 0 ? cus : 256;
 }
-// Launch bracket: drop whatever error an unrelated earlier call left on this thread, launch, then report
-// only this launch's own status.
-#define FA_LAUNCH(...)                         \
-    do {                                       \
-        (void)hipGetLastError();               \
-        hipLaunchKernelGGL(__VA_ARGS__);       \
-    } while (0)
+// Launch: hipLaunchKernel's own return value is this launch's status.  Nothing is cleared and nothing is read from the
+// thread's sticky last-error slot, so an error the host application has pending (a failed launch of its own that it has
+// not looked at yet) is neither hidden nor mistaken for ours.  launch_status() = the status of this thread's latest FA_LAUNCH.
+inline thread_local hipError_t g_launch_status = hipSuccess;
+static inline hipError_t launch_status() { return g_launch_status; }
+template <typename... KArgs, typename... Args, size_t... I>
+static inline void launch_k_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                 std::index_sequence<I...>, Args&&... args) {
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};   // the kernel's exact parameter types, in order
+    void* ptrs[] = {static_cast<void*>(&std::get<I>(vals))...};
+    g_launch_status = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, stream);
+}
+template <typename... KArgs, typename... Args>
+static inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count does not match the kernel's parameter list");
+    launch_k_impl(kernel, grid, block, lds, stream, std::index_sequence_for<KArgs...>{}, static_cast<Args&&>(args)...);
+}
+#define FA_LAUNCH(...) ::fa::launch_k(__VA_ARGS__)
 
 }  // namespace fa

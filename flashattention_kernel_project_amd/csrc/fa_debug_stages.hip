@@ -192,7 +192,7 @@ static hipError_t debug_stage_t(int stage, const void* A, const void* B, void* O
         if (D == 64) FA_LAUNCH((fa_debug_pv_kernel<T, 64>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb);
         else         FA_LAUNCH((fa_debug_pv_kernel<T, 128>), dim3((unsigned)nwg), dim3(256), 0, stream, a, b, static_cast<float*>(Out), N, nqb);
     }
-    return hipGetLastError();
+    return launch_status();
 }
 
 // stage 1: A = Q, B = K, Out = S fp32 [BH,N,N].  stage 2: A = S fp32, B unused, Out = P 16-bit [BH,N,N].

@@ -611,7 +611,7 @@ static hipError_t launch_il(const void* Q, const void* K, const void* V, void* O
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e,
                        static_cast<unsigned long long*>(nullptr), (unsigned)nwg);
-    return hipGetLastError();
+    return launch_status();
 }
 
 #ifdef FA_EXPERIMENTS
@@ -644,7 +644,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
             case 31: go(fa_fwd_il_kernel<F16, 64, true, 4, false, 31>); break;
             default: return hipErrorInvalidValue;
         }
-        return hipGetLastError();
+        return launch_status();
     }
     if (waves >= 100) {   // the same ablations WITHOUT the in-kernel stamps (time them with events)
         const int nqb = (N + 255) / 256;
@@ -673,7 +673,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
             case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, false, 3>); break;
             default: return hipErrorInvalidValue;
         }
-        return hipGetLastError();
+        return launch_status();
     }
     if (waves >= 10) {   // 8-wave workgroups with one piece of the iteration removed (timing only, wrong results)
         const int nqb = (N + 255) / 256;
@@ -695,7 +695,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
             case 3: go(fa_fwd_il_kernel<F16, 64, true, 8, true, 3>); break;
             default: return hipErrorInvalidValue;
         }
-        return hipGetLastError();
+        return launch_status();
     }
     if (waves == 8) {
         const int nqb = (N + 255) / 256;
@@ -708,7 +708,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
                            static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                            static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, diag, 0u);
     }
-    return hipGetLastError();
+    return launch_status();
 }
 #endif  // FA_EXPERIMENTS
 

@@ -407,7 +407,7 @@ static hipError_t launch_tiled(const void* Q, const void* K, const void* V, void
     FA_LAUNCH(kern, dim3((unsigned)nwg), dim3(64 * W), G::kLdsBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e);
-    return hipGetLastError();
+    return launch_status();
 }
 
 template <typename T, bool kOutF32, bool kCausal = false>
@@ -420,7 +420,7 @@ static hipError_t launch_generic(const void* Q, const void* K, const void* V, vo
     FA_LAUNCH((fa_fwd_generic_kernel<T, kOutF32, kCausal>), dim3((unsigned)nwg), dim3(64), 0, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, D, nqb, scale * kLog2e);
-    return hipGetLastError();
+    return launch_status();
 }
 
 template <typename T, bool kOutF32>
@@ -454,25 +454,9 @@ static hipError_t dispatch_causal_d(const void* Q, const void* K, const void* V,
     return launch_generic<T, kOutF32, true>(Q, K, V, O, BH, N, D, scale, stream);
 }
 
-hipError_t pipe_dispatch(const void* Q, const void* K, const void* V, void* O,
-                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
-                         hipStream_t stream);
-
-hipError_t pp_dispatch(const void* Q, const void* K, const void* V, void* O,
-                       int BH, int N, int D, float scale, int in_dtype, int out_dtype,
-                       hipStream_t stream);
-
 hipError_t il_dispatch(const void* Q, const void* K, const void* V, void* O,
                        int BH, int N, int D, float scale, int in_dtype, int out_dtype, int waves,
                        hipStream_t stream);
-
-hipError_t tlp_dispatch(const void* Q, const void* K, const void* V, void* O,
-                        int BH, int N, int D, float scale, int in_dtype, int out_dtype, int occ,
-                        hipStream_t stream);
-
-hipError_t il16_dispatch(const void* Q, const void* K, const void* V, void* O,
-                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
-                         hipStream_t stream);
 
 hipError_t w64p_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype,
@@ -494,16 +478,9 @@ hipError_t rp_dispatch(const void* Q, const void* K, const void* V, void* O,
 hipError_t sk_dispatch(const void* Q, const void* K, const void* V, void* O,
                        int BH, int N, int D, float scale, int in_dtype, int out_dtype, int variant,
                        hipStream_t stream);
-hipError_t w64m_dispatch(const void* Q, const void* K, const void* V, void* O,
-                         int BH, int N, int D, float scale, int in_dtype, int out_dtype,
-                         hipStream_t stream);
 hipError_t w64_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
                                int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                                hipStream_t stream);
-hipError_t il2x16_dispatch(const void* Q, const void* K, const void* V, void* O,
-                           int BH, int N, int D, float scale, int in_dtype, int out_dtype,
-                           hipStream_t stream);
-
 // AUTO: the explicit algo id a shape resolves to (one rule for the dispatcher and for fa_selected_kernel()).
 //   d = 64, N > 256 and at least one 512-row workgroup per CU: the rolling half-tile pipeline on 16x16x32 with the folded
 //     fast pass (fa_fwd_rp16.hip, 24), fp16 and bf16.  Round 2, one device, interleaved A/B, B8 H16 N4096, ms per launch:
@@ -583,22 +560,16 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 22) return rp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
     if (algo == 25) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 3, stream);   // 24 with LDS-DMA staging
     if (algo >= 17 && algo <= 20) return sk_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo - 17, stream);   // A/B kernels AUTO never selects: only in libfa_mi355_exp.so (make experimental)
-    if (algo == 3) return pipe_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 4) return pp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 7 || algo == 8) {   // occupancy variants of the plain tiled kernel, fp16 d=64 fp32-out
         if (D != 64 || in_dtype != 0 || out_dtype != 0) return hipErrorInvalidValue;
         return algo == 7 ? launch_tiled<F16, 64, true, 4, 3>(Q, K, V, O, BH, N, scale, stream)
                          : launch_tiled<F16, 64, true, 4, 2>(Q, K, V, O, BH, N, scale, stream);
     }
-    if (algo == 12) return il2x16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (algo == 14) return w64p_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 15) return w64m_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 11) return il16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
-    if (algo == 9 || algo == 10)
-        return tlp_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, algo == 9 ? 3 : 4, stream);
 #else
     if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo == 25 || algo > 27) return hipErrorInvalidValue;
 #endif
+    if (algo == 3 || algo == 4 || (algo >= 9 && algo <= 12) || algo == 15) return hipErrorInvalidValue;   // ids of removed A/B kernels
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)
                               : dispatch_d<F16, false>(Q, K, V, O, BH, N, D, scale, algo, stream);

@@ -56,6 +56,10 @@ constexpr float kFoldMax = 24.0f;  // folded pass only while the reference maxim
 #ifndef FA_RP_ABL
 #define FA_RP_ABL 0   // timing ablations, wrong results (A/B builds only): 1 no LDS fragment reads in the loop, 8 no K/V staging, 16 no barrier
 #endif
+#ifndef FA_RP_SUMMFMA
+#define FA_RP_SUMMFMA 1          // 1: row sums of the optimistic passes on the matrix pipe: one v_mfma_f32_16x16x32 per packed-P fragment against a
+#endif                           // SELECTOR A operand (row 0 = ones over the k-groups of lanes 0-15 / 32-47, row 1 = ones over those of lanes 16-31 / 48-63):
+                                 // 4 accumulator registers and 16 pipe cycles instead of 16 v_add_f32 (or a 32x32x16 against ones: 16 registers, 32 cycles)
 #ifndef FA_RP_STAGE_SLOT
 #define FA_RP_STAGE_SLOT 8       // MFMA slot of the second step in front of which tile j+2 is written to LDS
 #endif
@@ -170,6 +174,26 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
     float m_ref[X] = {}, l_part[X] = {};
     u32x4 kst[kLoads], vst[kLoads];
     u32x4 frag[kRing];
+    // Row sums on the matrix pipe.  The packed P of a 32x32 score block (query lane & 31 on the lane, 8 keys in the 4 registers,
+    // the other 8 of the k-step in lane + 32) read as the B operand of a 16x16x32: column = lane & 15, k-group = lane >> 4.
+    // A = selector: row 0 adds k-groups 0 and 2 (queries 0..15), row 1 adds k-groups 1 and 3 (queries 16..31).  The result's
+    // rows 0 and 1 sit in lanes 0..15, registers 0 and 1: lsum[x][q >> 4] of lane q & 15 = row sum of query q of block x.
+    f32x4 lsum[X];
+    u32x4 sel;
+    {
+        const bool on = ((lane & 15u) == 0u && ((lane >> 4) & 1u) == 0u) || ((lane & 15u) == 1u && ((lane >> 4) & 1u) == 1u);
+        const unsigned w = on ? T::kOnes2 : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sel[i] = w; asm volatile("" : "+v"(sel[i])); }
+    }
+    auto sum_mfma = [&](f32x4 acc, u32x4 pk) -> f32x4 {
+        if constexpr (T::id == 0) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sel), __builtin_bit_cast(f16x8, pk), acc, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sel), __builtin_bit_cast(bf16x8, pk), acc, 0, 0, 0);
+    };
+    auto lsum_row = [&](int x) -> float {   // this lane's query: lsum[x][r >> 4] of lane r & 15
+        const float a = __shfl(lsum[x][0], (int)(r & 15u), 64), b = __shfl(lsum[x][1], (int)(r & 15u), 64);
+        return (r & 16u) ? b : a;
+    };
 
     // LDS fragment addresses.  A K fragment of unit (tile slot offset `so`, key block kb), k-step ks;
     // a V^T fragment of unit (so, kb), head-dim block db, 16-key step ks2.
@@ -243,7 +267,8 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             constexpr int j = decltype(jc)::value, x = j >> 3, e = 2 * (j & 7);
             const unsigned w = T::pack2(s_cur[x][e], s_cur[x][e + 1]);
             pk_cur[x][(j & 7) >> 2][j & 3] = w;
-            if constexpr (FA_RP_DOT2) {
+            if constexpr (FA_RP_SUMMFMA) {
+            } else if constexpr (FA_RP_DOT2) {
                 ls[x][j & 1] = T::sum2(w, ls[x][j & 1]);
             } else {
                 ls[x][0] += s_cur[x][e];
@@ -284,6 +309,13 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             }
             if constexpr (FA_RP_SETPRIO) __builtin_amdgcn_s_setprio(1);
             issue_mfma(ic);
+            if constexpr (FA_RP_SUMMFMA) {   // the 2 X row-sum instructions of the step (pk_prev[x][ks2]), spread over it
+                constexpr int kEvery = 16 / (2 * X);
+                if constexpr (i % kEvery == kEvery - 1) {
+                    constexpr int n = i / kEvery, x = n >> 1, ks2 = n & 1;
+                    lsum[x] = sum_mfma(lsum[x], pk_prev[x][ks2]);
+                }
+            }
             if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
                 constexpr int f = i / X + kAhead;
                 if constexpr (f < kFrags) read_frag(std::integral_constant<int, f>{}, so_q, ko, so_v, ko);
@@ -295,8 +327,10 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
             sfor<j1 - j0>([&](auto dj) { valu_step(std::integral_constant<int, j0 + decltype(dj)::value>{}); });
         });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!FA_RP_SUMMFMA) {
 #pragma unroll
-        for (int x = 0; x < X; ++x) l_part[x] += ls[x][0] + ls[x][1];
+            for (int x = 0; x < X; ++x) l_part[x] += ls[x][0] + ls[x][1];
+        }
     };
 
     // One step of the tracked (fallback) pass: same data flow in plain program order, with the lazy
@@ -370,6 +404,7 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 #pragma unroll
             for (int db = 0; db < G::kDBlocks; ++db) o[x][db] = zero16;
             l_part[x] = 0.0f;
+            lsum[x] = f32x4{0.f, 0.f, 0.f, 0.f};
             pkB[x][0] = pkB[x][1] = zero4;   // "P(-1)" = 0 against the zeroed V of ring slot 3
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ------------
@@ -466,6 +501,12 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
 #pragma unroll
                     for (int x = 0; x < X; ++x) o[x][db] = T::mfma32(vf, pkB[x][ks2], o[x][db]);
                 }
+            if constexpr (FA_RP_SUMMFMA && !kTrack) {
+#pragma unroll
+                for (int x = 0; x < X; ++x)
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 2; ++ks2) lsum[x] = sum_mfma(lsum[x], pkB[x][ks2]);
+            }
         }
     };
 
@@ -480,7 +521,7 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         const float lo = (float)N * 0x1p-14f;
 #pragma unroll
         for (int x = 0; x < X; ++x) {
-            l_row[x] = l_part[x] + swap_halves(l_part[x]);
+            l_row[x] = FA_RP_SUMMFMA ? lsum_row(x) : l_part[x] + swap_halves(l_part[x]);
             bad = bad || !(l_row[x] < lim) || !(l_row[x] >= lo) || !(fabsf(m_ref[x]) <= kFoldMax);
         }
         bad = bad || q_bad != 0;
@@ -489,7 +530,7 @@ void fa_fwd_rp_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restric
         run(std::integral_constant<int, 1>{});
 #pragma unroll
         for (int x = 0; x < X; ++x) {
-            l_row[x] = l_part[x] + swap_halves(l_part[x]);
+            l_row[x] = FA_RP_SUMMFMA ? lsum_row(x) : l_part[x] + swap_halves(l_part[x]);
             bad = bad || !(l_row[x] < lim);
         }
     }
@@ -544,7 +585,7 @@ static hipError_t launch_rp(const void* Q, const void* K, const void* V, void* O
                        rp::kSlots * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // fold: 1 = folded fast pass where it exists (fp16, d = 64), 0 = exact passes only

@@ -84,6 +84,15 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #ifndef FA_RP16_RUNSUM
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
+#ifndef FA_RP16_VFIX
+#define FA_RP16_VFIX 0             // 1: the V image's 32-B key rows are XORed with the head-dim block (db & 3) inside their 256-B block, so that the
+#endif                             // eight lanes of a ds_write_b128 group (one key row, chunks 0..7) hit eight 16-B slots of the 128-B bank row
+#ifndef FA_RP16_VSPLIT
+#define FA_RP16_VSPLIT 0           // 1: a vector pair-step is spread over its matrix slots (one v_exp behind each of the first two, the v_cvt_pk
+#endif                             // behind the second / third) instead of all behind the last
+#ifndef FA_RP16_RAWBAR
+#define FA_RP16_RAWBAR 0           // 1: the tile barrier waits for this wave's staging writes only (counted lgkmcnt), not for the fragment reads behind them
+#endif
 #ifndef FA_RP16_STAGE_SLOT
 #define FA_RP16_STAGE_SLOT 8       // matrix slot (of 32; scaled for narrower steps) of the second step in front of which tile j+2 is written to LDS
 #endif
@@ -130,6 +139,15 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr int kSlots = kNF * X;             // matrix instructions per step (32 for the 64-row waves: X = 4 at D = 64, 2 at D = 128)
     static_assert(2 * kKS == kDB && kNF % kRing == 0 && kSlots % (4 * X) == 0, "fragment ring / vector pair-steps divide a step");
     constexpr int kLoads = (kBlockN * G::kChunks) / (64 * kW);   // 16-B chunks of K (and of V) per thread and tile
+    // LDS instructions a wave issues in the second step behind the landing of tile j+2 (fragment reads: one ds_read_b128 per K
+    // fragment, two ds_read_b64_tr_b16 per V^T fragment)
+    constexpr int kLandSlot = FA_RP16_STAGE_SLOT * kSlots / 32;
+    constexpr int kLdsAfterLand = [] {
+        int n = 0;
+        for (int i = kLandSlot; i < kSlots; ++i)
+            if (i % X == X - 1) n += ((i / X + kAhead) & 1) ? 2 : 1;
+        return n;
+    }();
     constexpr unsigned kRowB = D * 2;
     constexpr unsigned kTile = kBlockN * D * 2;
     constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
@@ -144,20 +162,29 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     const int ntiles = (N + kBlockN - 1) / kBlockN;
     const bool partial = (N % kBlockN) != 0;
 
-    unsigned st_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
+    unsigned st_goff[kLoads], sv_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
 #pragma unroll
     for (int p = 0; p < kLoads; ++p) {
         const unsigned idx = tid + p * 64u * kW;
-        const unsigned srow = idx / G::kChunks, sch = idx % G::kChunks;
+        unsigned srow = idx / G::kChunks, sch = idx % G::kChunks;
         st_goff[p] = srow * kRowB + sch * 16u;
         k_lds[p] = G::k_off(srow, sch);
-        v_lds[p] = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + ((srow & 7u) << 5) + ((sch & 1u) << 4);
+        if constexpr (FA_RP16_VFIX == 2) {
+            // V: the eight lanes of a ds_write_b128 group take 4 keys x 2 chunks of one head-dim block (128 contiguous bytes of
+            // the image) instead of one key's 8 chunks (8 slots 256 B apart: 4-way on the 128-B bank row of a write)
+            constexpr unsigned ndb = G::kChunks / 2, rpw = 64u / G::kChunks;   // head-dim blocks; key rows per wave-instruction
+            const unsigned w = idx >> 6, l = idx & 63u, t = l >> 3;
+            srow = w * rpw + 4u * (t / ndb) + ((l >> 1) & 3u);
+            sch = 2u * (t % ndb) + (l & 1u);
+        }
+        sv_goff[p] = srow * kRowB + sch * 16u;
+        v_lds[p] = kTile + ((srow >> 3) * (unsigned)kDB + (sch >> 1)) * 256u + (((srow & 7u) ^ (FA_RP16_VFIX == 1 ? ((sch >> 1) & 3u) : 0u)) << 5) + ((sch & 1u) << 4);
     }
     // LDS-DMA: this wave's 1-KB piece of an image is bytes [1024 wave, +1024), lane l lands at +16 l; where that comes from
     const unsigned dk_row = 8u * wave + (lane >> 3), dk_slot = lane & 7u;
     const unsigned k_src = dk_row * kRowB + ((dk_slot ^ G::k_swz(dk_row)) << 4);
     const unsigned dv_l = 1024u * wave + 16u * lane, dv_blk = dv_l >> 8;
-    const unsigned dv_row = (dv_blk / (unsigned)kDB) * 8u + ((dv_l & 255u) >> 5), dv_ch = (dv_blk % (unsigned)kDB) * 2u + ((dv_l >> 4) & 1u);
+    const unsigned dv_row = (dv_blk / (unsigned)kDB) * 8u + (((dv_l & 255u) >> 5) ^ (FA_RP16_VFIX == 1 ? ((dv_blk % (unsigned)kDB) & 3u) : 0u)), dv_ch = (dv_blk % (unsigned)kDB) * 2u + ((dv_l >> 4) & 1u);
     const unsigned v_src = dv_row * kRowB + dv_ch * 16u;
     typedef __attribute__((address_space(3))) void lds_void;
     auto dma_tile = [&](__amdgpu_buffer_rsrc_t rks, __amdgpu_buffer_rsrc_t rvs, unsigned tile_off, unsigned slot_off) __attribute__((always_inline)) {
@@ -167,7 +194,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     unsigned k_rd[kKS];
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) k_rd[ks] = c16 * kRowB + (((4u * ks + g) ^ G::k_swz(c16)) << 4);
-    const unsigned v_rd = kTile + (g >> 1) * (unsigned)kDB * 256u + ((4u * (g & 1u) + (c16 >> 2)) << 5) + (c16 & 3u) * 8u;
+    // (FA_RP16_VFIX: one base per db & 3 -- the key row inside the 256-B block is XORed with it)
+    unsigned v_rd4[4];
+#pragma unroll
+    for (unsigned dq = 0; dq < 4u; ++dq)
+        v_rd4[dq] = kTile + (g >> 1) * (unsigned)kDB * 256u + ((4u * (g & 1u) + ((c16 >> 2) ^ (FA_RP16_VFIX == 1 ? dq : 0u))) << 5) + (c16 & 3u) * 8u;
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const u32x4 zero4u = {0u, 0u, 0u, 0u};
@@ -265,11 +296,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 continue;
             }
             pfk[0][p] = buf_load16(rk_, st_goff[p]);
-            pfv[0][p] = buf_load16(rv_, st_goff[p]);
+            pfv[0][p] = buf_load16(rv_, sv_goff[p]);
             pfk[1][p] = buf_load16(rk_, kTile + st_goff[p]);
-            pfv[1][p] = buf_load16(rv_, kTile + st_goff[p]);
+            pfv[1][p] = buf_load16(rv_, kTile + sv_goff[p]);
             kst[p] = buf_load16(rk_, 2u * kTile + st_goff[p]);
-            vst[p] = buf_load16(rv_, 2u * kTile + st_goff[p]);
+            vst[p] = buf_load16(rv_, 2u * kTile + sv_goff[p]);
         }
     };
     constexpr unsigned kStores = (unsigned)(X * kDB);   // store instructions per item
@@ -386,7 +417,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         u32x4 vf;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const u32x2 half = lds_read_tr8(smem, so + v_rd + (4u * h + 2u * jj) * (unsigned)kDB * 256u + db * 256u);
+            const u32x2 half = lds_read_tr8(smem, so + v_rd4[FA_RP16_VFIX == 1 ? (db & 3) : 0] + (4u * h + 2u * jj) * (unsigned)kDB * 256u + db * 256u);
             vf[2 * jj] = half[0];
             vf[2 * jj + 1] = half[1];
         }
@@ -443,9 +474,20 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             s_cur[x][kbl][e] = fast_exp2(s_cur[x][kbl][e]);
             s_cur[x][kbl][e + 1] = fast_exp2(s_cur[x][kbl][e + 1]);
         };
+        auto fma_one = [&](auto jc, auto ec) {
+            constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1) + decltype(ec)::value;
+            s_cur[x][kbl][e] = __builtin_fmaf(s_cur[x][kbl][e], c, -m_ref[x]);
+        };
+        auto exp_one = [&](auto jc, auto ec) {   // (pinned: the value exists at this point of the stream, not where its consumer is)
+            constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1) + decltype(ec)::value;
+            float p = fast_exp2(s_cur[x][kbl][e]);
+            asm volatile("" : "+v"(p));
+            s_cur[x][kbl][e] = p;
+        };
         auto fin_pair = [&](auto jc) {
             constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
-            const unsigned w = T::pack2(s_cur[x][kbl][e], s_cur[x][kbl][e + 1]);
+            unsigned w = T::pack2(s_cur[x][kbl][e], s_cur[x][kbl][e + 1]);
+            if constexpr (FA_RP16_VSPLIT != 0) asm volatile("" : "+v"(w));
             pk_cur[x][2 * kbl + (j & 1)] = w;
             if constexpr (FA_RP16_SUMMFMA) {
             } else if constexpr (T::kSumRounded) {
@@ -492,7 +534,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         sfor<kSlots>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (h == 1 && i == FA_RP16_STAGE_SLOT * kSlots / 32 && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
+            if constexpr (h == 1 && i == kLandSlot && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
                     lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
@@ -511,7 +553,18 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
             }
             constexpr int kPer = kSlots / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
-            if constexpr (i % kPer == (FA_RP16_VALU_AT ? 0 : kPer - 1)) valu_step(std::integral_constant<int, i / kPer>{});
+            if constexpr (FA_RP16_VSPLIT != 0 && (FA_RP16_ABL & 2) == 0) {
+                // the pair-step's instructions one by one behind consecutive matrix instructions: a v_exp (or v_cvt_pk) of ~8 issue
+                // cycles fits in the shadow of the 16-cycle matrix instruction in front of it, three in a row do not
+                constexpr int j = i / kPer, sub = i % kPer;
+                if constexpr (sub < 2) {
+                    if constexpr (j + 2 < kPairs && !kFast) fma_one(std::integral_constant<int, j + 2>{}, std::integral_constant<int, sub>{});
+                    if constexpr (j + 1 < kPairs) exp_one(std::integral_constant<int, j + 1>{}, std::integral_constant<int, sub>{});
+                }
+                if constexpr (sub == (kPer == 2 ? 1 : 2)) fin_pair(std::integral_constant<int, j>{});
+            } else {
+                if constexpr (i % kPer == (FA_RP16_VALU_AT ? 0 : kPer - 1)) valu_step(std::integral_constant<int, i / kPer>{});
+            }
         });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!FA_RP16_RUNSUM) {
@@ -700,7 +753,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
                     kst[p] = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff[p]);
-                    vst[p] = buf_load16(rv, (unsigned)(j + 2) * kTile + st_goff[p]);
+                    vst[p] = buf_load16(rv, (unsigned)(j + 2) * kTile + sv_goff[p]);
                 }
             }
             if constexpr (kTrack) {
@@ -712,7 +765,19 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 step(c0{}, masked_c, fast_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p2);
                 step(c1{}, masked_c, fast_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p2);
             }
-            if constexpr ((FA_RP16_ABL & 16) == 0) __syncthreads();
+            if constexpr ((FA_RP16_ABL & 16) != 0) {
+            } else if constexpr (FA_RP16_RAWBAR != 0 && !kDma && !kTrack && kLdsAfterLand <= 15) {
+                // The barrier publishes this wave's ds_writes of tile j+2 (first read one iteration later) and orders the ring's
+                // reuse; it does not need the fragment reads issued since (LDS operations of a wave complete in order: once at
+                // most kLdsAfterLand are outstanding, the writes are done).  __syncthreads() would wait for all of them
+                // (s_waitcnt lgkmcnt(0)): the latency of the last read, exposed once per tile.
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(kLdsAfterLand) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                __syncthreads();
+            }
         };
         if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(3);
         using dyn = std::integral_constant<int, -1>;
@@ -901,7 +966,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb,
               scale * kLog2e, (unsigned)nwg);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // fold: 1 = folded fast pass (fp16), 0 = exact passes only; +2 = K/V staging by LDS-DMA

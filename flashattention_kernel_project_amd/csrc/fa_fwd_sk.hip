@@ -429,7 +429,7 @@ static hipError_t launch_sk(const void* Q, const void* K, const void* V, void* O
               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
               static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg,
               static_cast<unsigned long long*>(nullptr));
-    return hipGetLastError();
+    return launch_status();
 }
 
 #ifdef FA_EXPERIMENTS
@@ -446,7 +446,7 @@ hipError_t sk_diag_dispatch(const void* Q, const void* K, const void* V, void* O
         FA_LAUNCH(kern, dim3(grid), dim3(64 * sk::kW), 2 * G::kBufBytes, stream,
                   static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb,
                   scale * kLog2e, (unsigned)nwg, diag);
-        return hipGetLastError();
+        return launch_status();
     };
     switch (variant) {
         case 0: return go(fa_fwd_sk_kernel<F16, 64, 2, true, true, true, true>);

@@ -348,17 +348,17 @@ static hipError_t launch_split(const void* Q, const void* K, const void* V, void
     if (S == 1) {
         FA_LAUNCH((fa_fwd_split_kernel<T, D, kOutF32, false>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,
                            stream, q, k, v, O, static_cast<float*>(nullptr), Nq, Nk, nqb, S, chunk, scale * kLog2e);
-        return hipGetLastError();
+        return launch_status();
     }
     FA_LAUNCH((fa_fwd_split_kernel<T, D, kOutF32, true>), dim3((unsigned)nwg), dim3(64 * split::kW), G::kLdsBytes,
                        stream, q, k, v, O, static_cast<float*>(ws), Nq, Nk, nqb, S, chunk, scale * kLog2e);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_status();
     if (e != hipSuccess) return e;
     const long long rows = (long long)BH * Nq;   // one wave per output row
     if (rows > 0x7FFFFFFFll) return hipErrorInvalidValue;
     FA_LAUNCH((fa_split_combine_kernel<T, kOutF32>), dim3((unsigned)rows), dim3(64), 0, stream,
                        static_cast<const float*>(ws), O, BH, Nq, D, S);
-    return hipGetLastError();
+    return launch_status();
 }
 
 hipError_t split_dispatch(const void* Q, const void* K, const void* V, void* O, void* ws, size_t ws_bytes,

@@ -402,7 +402,7 @@ static hipError_t launch_w64(const void* Q, const void* K, const void* V, void* 
     FA_LAUNCH((fa_fwd_w64_kernel<T, D, X, kOutF32, kCausal, kW>), dim3(grid), dim3(64 * kW), 2 * FA_W64_BARRIER_EVERY * G::kBufBytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
-    return hipGetLastError();
+    return launch_status();
 }
 
 template <bool kCausal>

@@ -368,7 +368,7 @@ static hipError_t launch_w64x(const void* Q, const void* K, const void* V, void*
     FA_LAUNCH((fa_fwd_w64x_kernel<T, D, X, kOutF32>), dim3(grid), dim3(64 * w64x::kW), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K),
                        static_cast<const uint16_t*>(V), O, N, nqb, scale * kLog2e, (unsigned)nwg);
-    return hipGetLastError();
+    return launch_status();
 }
 
 #ifndef FA_W64X_X64

@@ -352,7 +352,7 @@ static hipError_t launch(const void* Q, const void* K, const void* V, void* O, i
     FA_LAUNCH((lab_w64x_kernel<kStruct, kSkew, kAbl, kDiag>), dim3(grid), dim3(64 * kW), lds_bytes, stream,
                        static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V),
                        static_cast<float*>(O), N, nqb, scale * kLog2e, (unsigned)nwg, diag);
-    return hipGetLastError();
+    return launch_status();
 }
 
 }  // namespace lab

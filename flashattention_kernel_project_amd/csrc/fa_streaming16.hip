@@ -106,7 +106,7 @@ hipError_t streaming16_dispatch(const void* Q, const void* K, const void* V, flo
     else
         FA_LAUNCH(fa_streaming16_kernel<false>, dim3(grid), dim3(64 * kS16WavesPerBlock), 0, stream,
                            (const uint16_t*)Q, (const uint16_t*)K, (const uint16_t*)V, O, num_batches, seq_len, c);
-    return hipGetLastError();
+    return launch_status();
 }
 
 }  // namespace fa

@@ -27,6 +27,16 @@ def _stream_ptr(stream):
     return getattr(stream, "cuda_stream", stream)
 
 
+def _one_device(*tensors):
+    """All tensors on one GPU; returns it.  The C side launches on (and reads the CU count / sets the LDS
+    attribute of) the CURRENT device, so every entry point below makes the tensors' device current."""
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t is not None and t.device != dev:
+            raise ValueError("all tensors of one call must live on one device")
+    return dev
+
+
 def _dev_ptr(t, name: str, dtypes):
     if not t.is_cuda:
         raise ValueError(f"{name} must be a device tensor (the HIP path has no CPU fallback)")
@@ -47,10 +57,10 @@ def flashattn_forward_wmma(Q, K, V, O, BH: int, N: int, D: int, scale: float, st
             raise ValueError(f"{name} has {t.numel()} elements, expected BH*N*D = {BH * N * D}")
     if O.numel() != BH * N * D:
         raise ValueError("O has the wrong number of elements")
-    code = capi.lib().flashattn_forward_wmma(
-        _dev_ptr(Q, "Q", (torch.float16,)), _dev_ptr(K, "K", (torch.float16,)),
-        _dev_ptr(V, "V", (torch.float16,)), _dev_ptr(O, "O", (torch.float32,)),
-        BH, N, D, float(scale), _stream_ptr(stream))
+    ptrs = (_dev_ptr(Q, "Q", (torch.float16,)), _dev_ptr(K, "K", (torch.float16,)),
+            _dev_ptr(V, "V", (torch.float16,)), _dev_ptr(O, "O", (torch.float32,)))
+    with torch.cuda.device(_one_device(Q, K, V, O)):
+        code = capi.lib().flashattn_forward_wmma(*ptrs, BH, N, D, float(scale), _stream_ptr(stream))
     capi.check("flashattn_forward_wmma", code)
 
 
@@ -87,9 +97,7 @@ def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = 
         scale = 1.0 / math.sqrt(d)
     dts = (torch.float16, torch.bfloat16)
     fn_name = "fa_forward_causal" if causal else "fa_forward_ex"
-    if not (q.device == k.device == v.device == out.device):
-        raise ValueError("q, k, v and out must live on one device")
-    with torch.cuda.device(q.device):   # the launch goes to the CURRENT device: make that the tensors' device
+    with torch.cuda.device(_one_device(q, k, v, out)):   # the launch goes to the CURRENT device: make that the tensors' device
         code = getattr(capi.lib(), fn_name)(
             _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts),
             _dev_ptr(out, "out", (out_dtype,)), B, H, N, d, float(scale), in_dt, out_dt, algo,
@@ -120,17 +128,19 @@ def fa_forward_splitkv(q, k, v, scale: float | None = None, out_dtype=None, work
     if out_dtype not in (torch.float32, q.dtype):
         raise ValueError("out_dtype must be torch.float32 or the input dtype")
     out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
-    need = splitkv_workspace_bytes(B, H, rows, Nk, d)
+    with torch.cuda.device(q.device):   # the split count follows the CU count of the device that will run it
+        need = splitkv_workspace_bytes(B, H, rows, Nk, d)
     if workspace is None and need:
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
     ws_ptr, ws_len = (workspace.data_ptr(), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
     if scale is None:
         scale = 1.0 / math.sqrt(d)
     dts = (torch.float16, torch.bfloat16)
-    code = capi.lib().fa_forward_splitkv(
-        _dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts), _dev_ptr(out, "out", (out_dtype,)),
-        B, H, rows, Nk, d, float(scale), in_dt, capi.OUT_F32 if out_dtype == torch.float32 else capi.OUT_SAME,
-        ws_ptr, ws_len, _stream_ptr(stream))
+    ptrs = (_dev_ptr(q, "q", dts), _dev_ptr(k, "k", dts), _dev_ptr(v, "v", dts), _dev_ptr(out, "out", (out_dtype,)))
+    with torch.cuda.device(_one_device(q, k, v, out, workspace)):
+        code = capi.lib().fa_forward_splitkv(
+            *ptrs, B, H, rows, Nk, d, float(scale), in_dt, capi.OUT_F32 if out_dtype == torch.float32 else capi.OUT_SAME,
+            ws_ptr, ws_len, _stream_ptr(stream))
     capi.check("fa_forward_splitkv", code)
     return out
 
@@ -144,10 +154,10 @@ def _streaming(fn_name: str, Q, K, V, O, num_batches: int, seq_len: int, scale: 
     if Q.numel() != num_batches * 256 or K.numel() != num_batches * 16 * seq_len \
             or V.numel() != num_batches * 16 * seq_len or O.numel() != num_batches * 256:
         raise ValueError("tensor sizes do not match num_batches/seq_len")
-    code = getattr(capi.lib(), fn_name)(
-        _dev_ptr(Q, "Q", (torch.float16,)), _dev_ptr(K, "K", (torch.float16,)),
-        _dev_ptr(V, "V", (torch.float16,)), _dev_ptr(O, "O", (torch.float32,)),
-        num_batches, seq_len, float(scale), _stream_ptr(stream))
+    ptrs = (_dev_ptr(Q, "Q", (torch.float16,)), _dev_ptr(K, "K", (torch.float16,)),
+            _dev_ptr(V, "V", (torch.float16,)), _dev_ptr(O, "O", (torch.float32,)))
+    with torch.cuda.device(_one_device(Q, K, V, O)):
+        code = getattr(capi.lib(), fn_name)(*ptrs, num_batches, seq_len, float(scale), _stream_ptr(stream))
     capi.check(fn_name, code)
 
 

@@ -51,16 +51,10 @@ extern "C" {
 #define FA_ALGO_W64X           16 /* round 1's default for fp16: the W64 stream on v_mfma_f32_16x16x32 */
 #define FA_ALGO_RP             21 /* the rolling pipeline on 32x32x16 (two 32-row blocks per wave), exact passes */
 #define FA_ALGO_RP_FOLD        22 /* RP with the folded fast pass (fp16, D = 64) */
-#define FA_ALGO_PIPE            3 /* TILED with QK^T of tile t+1 under the softmax of tile t, D = 64 */
-#define FA_ALGO_PINGPONG        4 /* two wave groups skewed by half a tile: MFMA phase beside softmax phase, D in {64,128} */
-#define FA_ALGO_TLP3            9 /* simple per-wave stream, three 128-row workgroups per CU, D = 64 */
-#define FA_ALGO_IL16           11 /* 16 waves x 16 rows on v_mfma_f32_16x16x32, D = 64 */
-#define FA_ALGO_IL2X16         12 /* 8 waves x two 16-row blocks sharing K/V fragments, 16x16x32, D = 64 */
 #define FA_ALGO_W64P           14 /* W64 with a half-tile rolling pipeline, packed fp32 (round 1's form of RP), D in {64,128} */
-#define FA_ALGO_W64M           15 /* W64 with QK^T one tile ahead, merged with PV into one matrix phase */
 #define FA_ALGO_RP16_DMA       25 /* RP16_FOLD with K/V staged by LDS-DMA (buffer_load ... lds) instead of through registers */
 #define FA_ALGO_SK             17 /* skewed halves: waves 4-7 half an iteration behind waves 0-3, folded fast pass; 18 exact, 19/20 lock-step */
-/* 7, 8, 10: occupancy variants of TILED (fp16, d=64). */
+/* 7, 8: occupancy variants of TILED (fp16, d=64).  3, 4, 9-12, 15 (round 1 / 2 A/B kernels two generations stale) were removed in round 3. */
 
 /* General-shape forward.  Replaces
  *   flashattn_forward_wmma_kernel(const half* Q, const half* K, const half* V, float* O,

@@ -35,8 +35,8 @@ def main():
     rng = random.Random(args.seed)
     g = torch.Generator(device="cuda").manual_seed(args.seed)
     exp = fa.lib().fa_mi355_has_experiments() == 1   # the A/B kernels exist only in libfa_mi355_exp.so (FA_MI355_LIB=...)
-    plain = {64: (0, 1, 2, 5, 6, 23, 24, 24, 24, 26, 26, 27, 27) + ((3, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 25) if exp else ()),
-             128: (0, 1, 2, 23, 24, 24, 26, 26) + ((4, 13, 14, 15, 16, 21) if exp else ())}
+    plain = {64: (0, 1, 2, 5, 6, 23, 24, 24, 24, 26, 26, 27, 27) + ((13, 14, 16, 17, 18, 19, 20, 21, 22, 25) if exp else ()),
+             128: (0, 1, 2, 23, 24, 24, 26, 26) + ((13, 14, 16, 21) if exp else ())}
     caus = {64: (0, 1, 2, 6, 24, 24) + ((13,) if exp else ()), 128: (0, 1, 2, 6, 24, 24) + ((13,) if exp else ())}
     t0, cases, fails, worst = time.time(), 0, 0, 0.0
     next_note = t0 + 60.0
@@ -75,8 +75,7 @@ def main():
         torch.cuda.synchronize()
         err = (got.float() - want).abs().max().item()
         # 1e-2 (north-star) plus what the 16-bit formats themselves impose on peaked rows (O ~ one V row):
-        # a bf16 OUTPUT rounds by |O| * 2^-9; the A/B kernels that sum the un-rounded bf16 weights
-        # (3, 4, 9, 10, 11, 12) reproduce |V| * 2^-9 of the dominant weight's rounding.
+        # a bf16 OUTPUT rounds by |O| * 2^-9.
         vmax = v.float().abs().max().item()
         tol = 1e-2
         if dt == torch.bfloat16 and (spread > 2 or (kind == "causal")):
@@ -86,8 +85,6 @@ def main():
             tol += vmax * 2.0 ** -9
         if out_same:
             tol += vmax * (2.0 ** -9 if dt == torch.bfloat16 else 2.0 ** -12)
-        if dt == torch.bfloat16 and kind != "split" and algo in (3, 4, 9, 10, 11, 12):
-            tol += vmax * 2.0 ** -9
         cases += 1
         if time.time() >= next_note:   # a silent GPU job is taken to be hung
             print(f"... {cases} cases, {fails} failures so far", flush=True)
@@ -96,7 +93,7 @@ def main():
         if not (err <= tol) or not torch.isfinite(got).all():
             fails += 1
             print(f"FAIL err={err:.3e} tol={tol:.0e}: {desc}", flush=True)
-    print(f"fuzz: {cases} cases in {time.time() - t0:.0f} s, {fails} failures, worst max-abs {worst:.3e}", flush=True)
+    print(f"fuzz: seed {args.seed} library {os.path.basename(__import__("flashattention_kernel_project_amd.capi", fromlist=["x"]).LIB_PATH)} ({fa.version()}): {cases} cases in {time.time() - t0:.0f} s, {fails} failures, worst max-abs {worst:.3e}", flush=True)
     sys.exit(1 if fails else 0)
 
 

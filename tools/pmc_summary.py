@@ -32,4 +32,9 @@ for name, cs in acc.items():
                 out.append(f"{k[3:]} {a[k] / wc:.3f}")
     if "SQ_INSTS_VALU" in a:
         out.append(f"VALU insts {a['SQ_INSTS_VALU'] / 1e6:.1f} M")
+    if "--lds" in sys.argv:
+        out = out[:2]
+        for k in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_MFMA", "SQ_WAIT_INST_LDS", "SQ_INSTS_SALU"):
+            if k in a:
+                out.append(f"{k[3:]} {a[k] / 1e6:.2f} M")
     print("  ".join(out))
