@@ -24,6 +24,7 @@ hipError_t il_diag_dispatch(const void* Q, const void* K, const void* V, void* O
                             int BH, int N, float scale, unsigned long long* diag, int waves, hipStream_t stream);
 hipError_t sk_diag_dispatch(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale, int variant,
                             unsigned long long* diag, hipStream_t stream);
+hipError_t rp16_set_pass_ids(unsigned* dev_ptr);
 hipError_t lab_w64x_dispatch(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale,
                              int kstruct, int abl, unsigned long long* diag, hipStream_t stream);
 #endif
@@ -43,6 +44,9 @@ FA_EXPORT int fa_lab_w64x(const void* Q, const void* K, const void* V, void* O, 
 {
     return (int)fa::lab_w64x_dispatch(Q, K, V, O, BH, N, scale, kstruct, abl, diag, static_cast<hipStream_t>(stream));
 }
+
+// per-block pass ids of the fa_fwd_rp16 kernels (see g_rp16_pass_ids); nullptr switches the recording off again
+FA_EXPORT int fa_lab_rp16_pass_ids(unsigned* dev_ids) { return (int)fa::rp16_set_pass_ids(dev_ids); }
 
 // fa_fwd_sk (fp16 -> fp32, d = 64) with per-phase s_memtime stamps: diag[wg][wave][8]; variant 0 shipped, 1 no fold, 2 no skew, 3 neither
 FA_EXPORT int fa_lab_sk(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale, int variant,

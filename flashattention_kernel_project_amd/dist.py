@@ -51,6 +51,17 @@ class Ranks:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather(self, value: float, device=None) -> list:
+        """Every rank's value, in rank order, on every rank (the per-GPU figures of the bench line)."""
+        if self.world == 1:
+            return [value]
+        import torch
+        import torch.distributed as dist
+        mine = torch.tensor([value], dtype=torch.float64, device=device if self.backend == "nccl" else None)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
+
     def close(self) -> None:
         if self._pg:
             import torch.distributed as dist

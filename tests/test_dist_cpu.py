@@ -44,6 +44,8 @@ def _worker(rank, world, port, out_dir):
     total = ranks.sum_over_ranks(float(b1 - b0))
     assert worst >= wall - 1e-9 and worst >= 0.1 - 1e-3     # everybody sees the slowest rank's time
     assert total == bh
+    per_rank = ranks.gather(float(b1 - b0))                 # the bench line's per-GPU list: every rank's own figure, rank order
+    assert per_rank == [4.0, 3.0]
     np.save(os.path.join(out_dir, f"shard{rank}.npy"), result["o"])
     np.save(os.path.join(out_dir, f"range{rank}.npy"), np.array([b0, b1]))
     ranks.close()
@@ -71,5 +73,6 @@ def test_single_rank_needs_no_process_group(fa):
     r = Ranks()
     assert (r.rank, r.world) == (0, 1)
     assert r.max_over_ranks(1.5) == 1.5
+    assert r.gather(2.5) == [2.5]
     t = timed_region(r, lambda: None, lambda: None)
     assert 0 <= t < 0.5

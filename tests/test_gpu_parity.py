@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 
 MAX_ABS = 1e-2                       # north-star tolerance
 REL_L2 = {0: 2e-3, 1: 1.2e-2}        # fp16 / bf16 inputs (P is rounded to the input type)
+P_EPS = {0: 2.0 ** -11, 1: 2.0 ** -8}  # largest relative rounding error of one weight in the 16-bit format P is packed to (half an ulp at 1.0)
+
+
+def _peaked_tol(fmt, vmax, kernels=1):
+    """The tolerance model of tools/fuzz_gpu.py, for inputs that make sharply PEAKED rows (large logits, the first
+    rows under the causal mask): the north-star bar plus what the 16-bit format of P itself imposes.  A row whose
+    weight sits on two or three comparable keys moves by at most (relative rounding of one weight, P_EPS) x (the
+    spread of the dominant V rows, <= 2 vmax, of which a convex combination keeps at most vmax).  `kernels` = how many
+    independently rounding kernels the difference is taken between (2 when comparing two of ours with each other)."""
+    return MAX_ABS + kernels * float(vmax) * P_EPS[fmt]
 
 
 @pytest.fixture(scope="module")
@@ -54,11 +64,11 @@ def _algos_for(d):
     return tuple(a for a in algos if a not in _EXPERIMENTAL or _have_exp())
 
 
-def _check(oracle, got, want, fmt, what, out_same=False, max_abs=MAX_ABS):
+def _check(oracle, got, want, fmt, what, out_same=False, max_abs=MAX_ABS, rel_l2=None):
     ma = oracle.max_abs(got, want)
     rl = oracle.rel_l2(got, want)
     assert np.isfinite(got).all(), what
-    tol_rl = REL_L2[fmt] * (1.5 if out_same else 1.0)
+    tol_rl = rel_l2 if rel_l2 is not None else REL_L2[fmt] * (1.5 if out_same else 1.0)
     assert ma <= max_abs and rl <= tol_rl, f"{what}: max_abs={ma:.3e} rel_l2={rl:.3e}"
 
 
@@ -161,7 +171,7 @@ def test_extreme_logits_stay_finite(fa, oracle, torch_cuda):
     for algo in (0, 1):
         got = _run(fa, torch_cuda, qb, kb, vb, 0, algo)
         assert np.isfinite(got).all()
-        assert oracle.max_abs(got, want) <= 2e-2   # near-one-hot rows: |dO| ~ |V| * dP
+        assert oracle.max_abs(got, want) <= _peaked_tol(0, np.abs(v).max())   # near-one-hot rows
 
 
 def test_bit_reproducible_and_head_independent(fa, oracle, torch_cuda):
@@ -577,12 +587,13 @@ def test_splitkv_grouped_query_heads(fa, oracle, torch_cuda):
 
 # ---------------------------------------------------------------- round 2: configs at their stated shapes, AUTO edges, the folded pass
 
-def _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, rows, what):
+def _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, rows, what, max_abs=MAX_ABS, rel_l2=None):
     """q,k,v,o: [B,H,N,d] device tensors; rows: list of (b, h, r0, n) row ranges checked against the oracle."""
     for (b, h, r0, n) in rows:
         qs, ks, vs = (t[b, h].float().cpu().numpy()[None] for t in (q, k, v))
         want = oracle.forward(qs, ks, vs, accum=0, nthreads=8, row_range=(r0, r0 + n))
-        _check(oracle, o[b, h, r0:r0 + n].float().cpu().numpy(), want[0, r0:r0 + n], fmt, f"{what} b={b} h={h} rows {r0}..{r0 + n}")
+        _check(oracle, o[b, h, r0:r0 + n].float().cpu().numpy(), want[0, r0:r0 + n], fmt, f"{what} b={b} h={h} rows {r0}..{r0 + n}",
+               max_abs=max_abs, rel_l2=rel_l2)
 
 
 def test_cfg3_exact_shape_through_auto(fa, oracle, torch_cuda):
@@ -708,19 +719,52 @@ def test_folded_pass_gates(fa, oracle, torch_cuda, fmt):
         want = oracle.forward(q, k, v, accum=1, nthreads=8, **({} if scale is None else {"scale": scale}))
         for algo in (a for a in (24, 26, 27, 23, 22, 21, 0) if a not in _EXPERIMENTAL or _have_exp()):
             got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo, scale=scale)
-            _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo} fmt={fmt}", max_abs=MAX_ABS * (1.0 if fmt == 0 else 2.5))
+            _check(oracle, got, want, fmt, f"folded-pass gate: {name} algo={algo} fmt={fmt}",
+                   max_abs=MAX_ABS if fmt == 0 else _peaked_tol(fmt, np.abs(v).max()))
+
+
+def _pass_ids(torch, q, k, v, algo):
+    """Which pass produced each 512-row block (libfa_mi355_exp.so only: fa_lab_rp16_pass_ids): 0 folded fast pass, 1 exact
+    optimistic pass, 2 running-max pass in the kernel, 3 left to the redo kernel."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "flashattention_kernel_project_amd", "libfa_mi355_exp.so")
+    assert os.path.exists(path), "make -C flashattention_kernel_project_amd/csrc experimental (build() does it)"
+    from flashattention_kernel_project_amd import capi
+    capi._share_torch_hip_runtime()
+    L = C.CDLL(path)
+    L.fa_forward_ex.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3 + [C.c_void_p]
+    L.fa_lab_rp16_pass_ids.argtypes = [C.c_void_p]
+    B, H, N, d = q.shape
+    ids = torch.full((B * H * ((N + 511) // 512),), 255, dtype=torch.int32, device="cuda")
+    out = torch.empty(q.shape, dtype=torch.float32, device="cuda")
+    assert L.fa_lab_rp16_pass_ids(ids.data_ptr()) == 0
+    try:
+        rc = L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, N, d, 1.0 / d ** 0.5,
+                             0 if q.dtype == torch.float16 else 1, 0, algo, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        assert L.fa_lab_rp16_pass_ids(None) == 0
+    return ids.cpu().numpy(), out
 
 
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda, fmt):
-    """N(0,1) inputs at the bench shape: the folded pass is taken (no gate fires) and its output stays within the
+    """N(0,1) inputs at the bench shape: the folded pass IS the pass that runs (asserted through the experimental build's
+    per-block pass ids: at least 99 % of the blocks, no block left to the redo kernel) and its output stays within the
     tolerance of the exact pass on every element."""
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(7)
     q, k, v = (torch.randn(2, 16, 4096, 64, generator=g, device="cuda").to(_tdtype(torch, fmt)) for _ in range(3))
+    ids, a_exp = _pass_ids(torch, q, k, v, 24)
+    assert (ids == 0).mean() >= 0.99 and (ids <= 1).all(), np.bincount(ids, minlength=4)
+    ids23, _ = _pass_ids(torch, q, k, v, 23)
+    assert (ids23 == 1).all(), np.bincount(ids23, minlength=4)   # the exact kernel: its optimistic pass, never the running max, on this data
     a = fa.fa_forward(q, k, v, algo=24)
     b = fa.fa_forward(q, k, v, algo=23)
     torch.cuda.synchronize()
+    assert torch.equal(a, a_exp)   # the experimental build's kernel is the product's
     tol = 2e-3 if fmt == 0 else 6e-3
     assert float((a - b).abs().max()) <= tol
     if _have_exp():
@@ -746,11 +790,12 @@ def test_folded_pass_spread_inputs_all_widths(fa, oracle, torch_cuda, fmt):
                 o = fa.fa_forward(q, k, v, algo=algo)
                 torch.cuda.synchronize()
                 assert bool(torch.isfinite(o).all()), (d, spread, algo)
-                # peaked rows: a 16-bit weight moves O by 2^-11 (2^-8) of the spread of the dominant V rows
-                assert float((o - exact).abs().max()) <= (4e-3 if fmt == 0 else 3e-2), (d, spread, algo)
-                if fmt == 0:
-                    _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, [(0, 0, 0, 16), (1, 2, 1084, 16), (1, 1, 500, 8)],
-                                        f"spread {spread} d={d} algo={algo}")
+                # two of our kernels against each other: each rounds its weights once (the bar itself does not enter)
+                vmax = float(v.float().abs().max())
+                assert float((o - exact).abs().max()) <= _peaked_tol(fmt, vmax, kernels=2) - MAX_ABS + 1e-3, (d, spread, algo)
+                _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, [(0, 0, 0, 16), (1, 2, 1084, 16), (1, 1, 500, 8)],
+                                    f"spread {spread} d={d} algo={algo}", max_abs=MAX_ABS if fmt == 0 else _peaked_tol(fmt, vmax),
+                                    rel_l2=None if fmt == 0 else 3e-2)
 
 
 def test_bench_two_rank_rehearsal():
@@ -770,6 +815,10 @@ def test_bench_two_rank_rehearsal():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
+    # "per-GPU and aggregate" (north_star, config 5): every rank's own figure and the sum, for the metric shape and for config 5's shard
+    assert len(rec["per_rank_tflops"]) == 2 and all(x > 0 for x in rec["per_rank_tflops"])
+    c5 = rec["cfg5_per_gpu"]
+    assert len(c5["per_rank_tflops"]) == 2 and c5["tflops_all_gpus"] > c5["tflops_per_gpu"] > 0 and c5["launches"] >= 30
 
 
 def test_native_harness_check_step():
@@ -809,7 +858,47 @@ def test_causal_large_grid_item_order(fa, oracle, torch_cuda, fmt):
             s = s.masked_fill(~torch.ones(n, n, dtype=torch.bool, device="cuda").tril_(), float("-inf"))
             want = torch.softmax(s, dim=-1) @ v.float()
             err = float((o - want).abs().max())
-            assert err <= MAX_ABS * (1.0 if fmt == 0 else 2.0), (bh, n, d, algo, err)
+            # (bf16 under the mask: the first rows have two or three keys -- peaked by construction)
+            assert err <= (MAX_ABS if fmt == 0 else _peaked_tol(fmt, float(v.float().abs().max()))), (bh, n, d, algo, err)
             del s, want, o
         del q, k, v
         torch.cuda.empty_cache()
+
+
+def test_microbenchmarks():
+    """the CDNA4 profiling micro-benchmarks build (make -C tools/microbench) and report sane figures --
+    matrix-only slots keep the pipe >= 95 % busy, the vector issue costs sit where the kernel's issue model puts them, the
+    sustained fp16 MFMA rate is a plausible fraction of the 2.5 PF peak, and the K/V stream alone (staging + barrier, no
+    matrix or vector work: the counterpart of flashattn_forward_cp_async_stall.cu:93-206) moves several TB/s into LDS."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mb = os.path.join(root, "tools", "microbench")
+    subprocess.check_call(["make", "-C", mb], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def run(*cmd):
+        out = subprocess.run([os.path.join(mb, cmd[0])] + list(cmd[1:]), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return out.stdout
+
+    slot = run("slot_model")
+    for shape in ("MFMA 32x32x16 only", "2 x MFMA 16x16x32 only"):
+        m = re.search(re.escape(shape) + r".*?2w:\s+([0-9.]+) cyc/slot \(\s*([0-9]+)% MFMA\)", slot)
+        assert m, slot[:2000]
+        assert 31.0 <= float(m.group(1)) <= 34.5 and int(m.group(2)) >= 95, (shape, m.groups())
+    m = re.search(r"2 x 16x16x32 \+ folded\s+1w:\s+([0-9.]+) cyc/slot.*?2w:\s+([0-9.]+) cyc/slot", slot)
+    assert m and 36.0 <= float(m.group(2)) <= 60.0, slot[:3000]   # the loop's floor: matrix issue + vector issue, serialised
+    valu = run("valu_rate")
+    for name, lo, hi in (("v_exp_f32", 7.0, 11.0), ("v_cvt_pk_f16_f32", 6.0, 10.5), ("v_fma_f32 (3 VGPR)", 3.5, 7.0)):
+        m = re.search(re.escape(name) + r"\s+1 waves/SIMD:\s+([0-9.]+) ticks", valu)
+        assert m and lo <= float(m.group(1)) <= hi, (name, m and m.group(1))
+    mf = run("mfma_power", "0.5")
+    rates = [float(x) for x in re.findall(r"mfma \d+x\d+: ([0-9.]+) TFLOP/s", mf)]
+    assert len(rates) == 4 and all(900.0 <= r <= 2600.0 for r in rates), mf
+    kv = run("kv_stream")
+    m0 = re.search(r"mode 0 .*?staged ([0-9.]+) TB/s", kv)
+    m1 = re.search(r"mode 1 .*?staged ([0-9.]+) TB/s", kv)
+    ml = re.search(r"LDS fragment reads ([0-9.]+) TB/s", kv)
+    assert m0 and m1 and ml, kv
+    assert float(m0.group(1)) >= 4.0, kv          # L2 -> LDS, staging + barrier only
+    assert float(ml.group(1)) >= 8.0 * float(m1.group(1)) * 0.99, kv

@@ -8,11 +8,12 @@ src=$root/flashattention_kernel_project_amd/csrc
 out=$root/gpurun_variants; obj=$out/obj_$name
 mkdir -p "$obj"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -fvisibility=hidden -Wall -Wno-unused-function"
-SRCS="fa_fwd_kernels.hip fa_fwd_il.hip fa_fwd_rp16.hip fa_fwd_split.hip fa_debug_stages.hip fa_streaming16.hip fa_capi.hip"
+SRCS="fa_fwd_kernels.hip fa_fwd_il.hip fa_fwd_rp16.hip fa_fwd_rp16_d64.hip fa_fwd_rp16_d64n.hip fa_fwd_rp16_d128.hip fa_fwd_rp16_c.hip fa_fwd_split.hip fa_debug_stages.hip fa_streaming16.hip fa_capi.hip"
 pids=()
 for s in $SRCS; do
   # only fa_fwd_sk.hip and fa_capi.hip depend on the knobs in practice; the rest are reused from the product build
-  if [ "$s" = "fa_fwd_rp.hip" ] || [ "$s" = "fa_fwd_rp16.hip" ] || [ "$s" = "fa_fwd_il.hip" ] || [ ! -f "$src/${s%.hip}.o" ]; then
+  # only the d = 64 full-width family depends on the FA_RP16_* knobs in practice (ALL=1 rebuilds every rp16 family); the rest are reused from the product build
+  if [ "$s" = "fa_fwd_rp16_d64.hip" ] || { [ -n "$ALL" ] && [[ "$s" == fa_fwd_rp16_* ]]; } || [ ! -f "$src/${s%.hip}.o" ]; then
     /opt/rocm/bin/hipcc $FLAGS $extra -c "$src/$s" -o "$obj/${s%.hip}.o" &
     pids+=($!)
   else
