@@ -238,7 +238,7 @@ def cpu_baseline(q, k, v, o_gpu, N, d, budget_s):
     # for a few seconds: it takes whole [BH,N,D] problems, so the sample is that head cut to its first n_ref rows AND keys
     reference = None
     if orc.have_ref():
-        n_ref = 1024 if N >= 1024 else N
+        n_ref = 2048 if N >= 2048 else N
         qr, kr, vr = (np_c(t[:, :n_ref]) for t in (q0, k0, v0))
         t0 = time.perf_counter()
         o_ref = orc.reference_forward(qr, kr, vr)

@@ -528,7 +528,7 @@ const char* algo_kernel_name(int algo, int D)
         case 16: return "fa::fa_fwd_w64x_kernel";
         case 21: case 22: return "fa::fa_fwd_rp_kernel";
 #endif
-        case 23: case 24: case 25: case 26: case 27: return "fa::fa_fwd_rp16_kernel";
+        case 23: case 24: case 25: case 26: case 27: case 28: return "fa::fa_fwd_rp16_kernel";
         default: return "";
     }
 }
@@ -549,6 +549,10 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (algo == 23) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 24) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
+    if (algo == 28) {   // d = 128 with one wave per SIMD (four 64-row waves, the whole register file each)
+        if (D != 128) return hipErrorInvalidValue;
+        return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1 | 12, stream);
+    }
     if (algo == 26 || algo == 27) {   // the pipeline on half-width / quarter-width waves (32 / 16 rows at D = 64, 16 at D = 128)
         if (D != 64 && !(D == 128 && algo == 26)) return hipErrorInvalidValue;
         return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1 | (algo == 26 ? 4 : 8), stream);
@@ -567,7 +571,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     }
     if (algo == 14) return w64p_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
 #else
-    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo == 25 || algo > 27) return hipErrorInvalidValue;
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo == 25 || algo > 28) return hipErrorInvalidValue;
 #endif
     if (algo == 3 || algo == 4 || (algo >= 9 && algo <= 12) || algo == 15) return hipErrorInvalidValue;   // ids of removed A/B kernels
     if (in_dtype == 0)

@@ -86,17 +86,24 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #define FA_RP16_RUNSUM 1           // 1: the optimistic passes keep their row-sum chains across steps (16 fewer v_add_f32 per tile)
 #endif
 #ifndef FA_RP16_VFIX
-#define FA_RP16_VFIX 0             // 1: the V image's 32-B key rows are XORed with the head-dim block (db & 3) inside their 256-B block, so that the
+#define FA_RP16_VFIX 2             // 1: the V image's 32-B key rows are XORed with the head-dim block (db & 3) inside their 256-B block, so that the
 #endif                             // eight lanes of a ds_write_b128 group (one key row, chunks 0..7) hit eight 16-B slots of the 128-B bank row
 #ifndef FA_RP16_VSPLIT
-#define FA_RP16_VSPLIT 0           // 1: a vector pair-step is spread over its matrix slots (one v_exp behind each of the first two, the v_cvt_pk
+#define FA_RP16_VSPLIT 1           // 1: a vector pair-step is spread over its matrix slots (one v_exp behind each of the first two, the v_cvt_pk
 #endif                             // behind the second / third) instead of all behind the last
 #ifndef FA_RP16_RAWBAR
-#define FA_RP16_RAWBAR 0           // 1: the tile barrier waits for this wave's staging writes only (counted lgkmcnt), not for the fragment reads behind them
+#define FA_RP16_RAWBAR 1           // 1: the tile barrier waits for this wave's staging writes only (counted lgkmcnt), not for the fragment reads behind them
+#endif
+#ifndef FA_RP16_PAIR
+#define FA_RP16_PAIR 1             // 1: narrow waves (X <= 2 at D = 64) run TWO tiles per barrier out of a ring of eight slots; 2: every D = 64 width (lab)
 #endif
 #ifndef FA_RP16_STAGE_SLOT
 #define FA_RP16_STAGE_SLOT 8       // matrix slot (of 32; scaled for narrower steps) of the second step in front of which tile j+2 is written to LDS
 #endif
+// Two tiles per loop iteration and barrier (ring of eight [K tile][V tile] slots, tiles landed three ahead instead of two): for
+// the narrow waves a tile is a few hundred issue cycles per wave, and the barrier of eight waves plus the landing of the next
+// tile cost as much again (stamps at B4 H8 N1024: 16 tiles took 13.8 us = 2000 cycles each).  D = 64 only (128 KB of LDS).
+constexpr bool pair_tiles(int D, int X, bool dma) { return FA_RP16_PAIR != 0 && D == 64 && !dma && (X <= 2 || FA_RP16_PAIR == 2); }
 }  // namespace rp16
 
 #ifdef FA_EXPERIMENTS
@@ -130,13 +137,21 @@ static hipError_t rp16_set_pass_ids_tu(unsigned* dev_ptr) { return hipMemcpyToSy
 // row blocks, finds the marked ones and computes them.  A marker that happens to equal a genuine output word (a NaN pattern no
 // kernel of ours produces) would only cause a block to be computed twice, with the same result; an unmarked failed block cannot
 // occur (the marker store is the failing workgroup's only store to the block).
-template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, bool kScan = false>
-__global__ __launch_bounds__(64 * rp16::kW, 2)
+// kWv: waves per workgroup.  8 = two per SIMD, 256 registers each (every shape above).  4 = ONE wave per SIMD with the whole
+// 512-register file (accumulators and Q in the upper half): at D = 128 that affords 64-row waves (X = 4), i.e. every LDS
+// fragment feeds four matrix instructions instead of two and four waves instead of eight read each tile -- the structure the
+// CDNA4 guide documents for d = 128 (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD"), built here on this stream.
+// (kWv = 4 with 16-row waves at D = 64 -- 64-row workgroups, two per CU -- was measured for small grids and lost: 23.5 against
+// 16.9 us at B4 H8 N1024, every workgroup stages every tile of its head.)
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, bool kScan = false, int kWv = 8>
+__global__ __launch_bounds__(64 * kWv, kWv == 8 ? 2 : 1)
 void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                         int N, int nqb, float scale_log2e, unsigned total_wg)
 {
     using namespace rp16;
+    constexpr int kW = kWv;   // (hides rp16::kW, the default)
+    static_assert(kWv == 8 || (kWv == 4 && !kDma && !kScan), "waves per workgroup: 8, or 4 (one per SIMD)");
     using M = Mx<T>;
     using G = TileGeom<D>;
     // The folded pass multiplies Q'.K on the fp16 matrix instruction whatever the input type: Q' = fp16(Q * scale * log2 e)
@@ -148,6 +163,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // full-width waves (64 rows at D = 64, 32 at D = 128): the running-max pass lives in the redo kernel (see kScan)
     constexpr bool kSplitTrack = !kScan && !kDma && 16 * X * (D / 64) >= 64;
     constexpr unsigned kMarker = 0x7FA5C0DEu;
+    constexpr bool kVSplit = FA_RP16_VSPLIT != 0 && !kCausal;   // (under the mask the pins cost the full-width kernels spills)
     static_assert(!(kCvtK && kDma), "the DMA path cannot convert K on the way");
     static_assert(!kDma || D == 64, "the DMA piece maps are written for 128-byte rows");
     constexpr int kRows = 16 * X * kW;
@@ -155,7 +171,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr int kNF = 2 * kKS + kDB;          // fragments per step (K and V^T alternate: 2 kKS == kDB)
     // fragment registers and read-ahead: a fragment feeds X matrix instructions, so the narrow waves (X < 4 at D = 64: small
     // grids) need more of them in flight to cover the LDS latency
-    constexpr bool kWide = 16 * X * (D / 64) >= 64;
+#ifndef FA_RP16_D128_DEEP
+#define FA_RP16_D128_DEEP 0        // lab: 32-row waves at D = 128 with the narrow waves' ring of eight fragment registers, read four ahead
+#endif                             // (a fragment there feeds two matrix instructions only: 2 ahead = 64 cycles of cover)
+    constexpr bool kWide = 16 * X * (D / 64) >= 64 && !(FA_RP16_D128_DEEP && D == 128);
     constexpr int kRing = kWide ? 4 : 8;
     constexpr int kAhead = kWide ? kAheadWide : (X == 2 ? 4 : 6);
     constexpr int kSlots = kNF * X;             // matrix instructions per step (32 for the 64-row waves: X = 4 at D = 64, 2 at D = 128)
@@ -173,6 +192,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr unsigned kRowB = D * 2;
     constexpr unsigned kTile = kBlockN * D * 2;
     constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
+    constexpr bool kPair = pair_tiles(D, X, kDma);
+    constexpr unsigned kRingSlots = kPair ? 8u : 4u, kRingMask = kRingSlots - 1u;
+    constexpr int kLook = kPair ? 3 : 2;            // a tile is landed this many tiles ahead of the iteration that starts with it
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of four slots
 
     const unsigned tid  = threadIdx.x;
@@ -281,10 +303,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // 2.2, gates 1.8, stores 1.6 of ~116 us per item at B8 H16 N4096).  kPrefetch: the NEXT item's Q rows are requested
     // (raw, into qf -- dead by then) as soon as the first pass' tile loop is over, i.e. ahead of this item's stores in the
     // in-order vector memory queue, and every item requests its first three K/V tiles before it waits for its Q.
-    constexpr bool kPrefetch = FA_RP16_PREFETCH != 0 && !kDma && !kScan;
+    constexpr bool kPrefetch = FA_RP16_PREFETCH != 0 && !kDma;
     constexpr bool kCarryKV = FA_RP16_PREFETCH == 2;   // lab: the K/V tiles 0..2 carried in registers as well (the allocator spills them)
     u32x4 qf[X][kKS];   // B operand of QK^T: Q[row of block x][32 ks + 8 g .. +7]
     u32x4 kst[kLoads], vst[kLoads];
+    u32x4 kst2[kLoads], vst2[kLoads];   // kPair: the second tile of an iteration
     u32x4 pfk[2][kLoads], pfv[2][kLoads];
     // hb: the head's Q; row_base: the wave's first row (wave-uniform, folded into the descriptor: the bounds check -- rows past
     // N read zeros -- covers the per-lane and the immediate offset only).  One per-lane address, recomputed here from the lane
@@ -325,39 +348,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             vst[p] = buf_load16(rv_, 2u * kTile + sv_goff[p]);
         }
     };
-    constexpr unsigned kStores = (unsigned)(X * kDB);   // store instructions per item
-    if constexpr (kPrefetch) {
-        // The first item's inputs, requested the way every later item's are (at the end of the item before it, ahead of that
-        // item's stores) -- including kStores stores, so that both ways into the loop look alike to the wait-count
-        // bookkeeping (s_waitcnt vmcnt counts in order: with the same instructions behind the loads on both paths the waits
-        // for Q and K/V can leave exactly the stores outstanding).  The stand-in stores put one zero chunk per wave on the first
-        // row the wave will really store later (same wave, same address, program order: the real value wins).
-        if (blockIdx.x < nwg) {
-            unsigned bh0, qb0;
-            locate(blockIdx.x, bh0, qb0);
-            bh0 = __builtin_amdgcn_readfirstlane(bh0);
-            qb0 = __builtin_amdgcn_readfirstlane(qb0);
-            const unsigned rb0 = qb0 * kRows + wave * (16u * X);
-            q_issue(Qg + bh0 * head_elems, rb0);
-            if constexpr (kCarryKV) kv_issue(make_rsrc(Kg + bh0 * head_elems, head_bytes), make_rsrc(Vg + bh0 * head_elems, head_bytes));
-            constexpr unsigned es0 = kOutF32 ? 4u : 2u;
-            const __amdgpu_buffer_rsrc_t ro0 =
-                make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh0 * head_elems * es0, (unsigned)(head_elems * es0));
-#pragma unroll
-            for (unsigned i = 0; i < kStores; ++i) {
-                u32x4 z = zero4u;
-                asm volatile("" : "+v"(z));
-                if constexpr (kOutF32) buf_store16(ro0, rb0 * D * 4u, z);
-                else buf_store8(ro0, rb0 * D * 2u, u32x2{z[0], z[1]});
-            }
-        }
-    }
     // kScan: the marked row blocks among those this workgroup owns (block b = blockIdx.x + i gridDim.x).  Thread t looks at the
     // t-th of them, all loads in flight together; the marked ones are collected in LDS behind the ring and computed in turn.
     constexpr unsigned kScanBatch = 64u * kW;
     unsigned scan_base = 0, scan_n = 0, scan_i = 0;
     auto scan_next = [&]() __attribute__((always_inline)) -> unsigned {
-        unsigned* list = reinterpret_cast<unsigned*>(smem + 4u * kSlotBytes);   // [0] = count, [1 ..] = block ids
+        unsigned* list = reinterpret_cast<unsigned*>(smem + kRingSlots * kSlotBytes);   // [0] = count, [1 ..] = block ids
         while (scan_i == scan_n) {
             if (blockIdx.x + scan_base * gridDim.x >= nwg) return nwg;
             __syncthreads();   // (every wave is done with the previous batch's list and with the ring)
@@ -381,7 +377,42 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         ++scan_i;
         return r;
     };
-    for (unsigned bid = kScan ? scan_next() : blockIdx.x; bid < nwg; bid = kScan ? scan_next() : bid + gridDim.x) {
+    // (the block after the current one, if the list already holds it: its Q rows are requested ahead, like the fast kernels do)
+    auto scan_peek = [&]() __attribute__((always_inline)) -> unsigned {
+        const unsigned* list = reinterpret_cast<const unsigned*>(smem + kRingSlots * kSlotBytes);
+        return scan_i < scan_n ? (unsigned)__builtin_amdgcn_readfirstlane(list[1u + scan_i]) : nwg;
+    };
+    const unsigned first_bid = kScan ? scan_next() : blockIdx.x;
+    [[maybe_unused]] bool q_pending = false;   // kScan: the current block's Q rows were requested by the block before it
+    constexpr unsigned kStores = (unsigned)(X * kDB);   // store instructions per item
+    if constexpr (kPrefetch) {
+        // The first item's inputs, requested the way every later item's are (at the end of the item before it, ahead of that
+        // item's stores) -- including kStores stores, so that both ways into the loop look alike to the wait-count
+        // bookkeeping (s_waitcnt vmcnt counts in order: with the same instructions behind the loads on both paths the waits
+        // for Q and K/V can leave exactly the stores outstanding).  The stand-in stores put one zero chunk per wave on the first
+        // row the wave will really store later (same wave, same address, program order: the real value wins).
+        if (first_bid < nwg) {
+            unsigned bh0, qb0;
+            locate(first_bid, bh0, qb0);
+            q_pending = true;
+            bh0 = __builtin_amdgcn_readfirstlane(bh0);
+            qb0 = __builtin_amdgcn_readfirstlane(qb0);
+            const unsigned rb0 = qb0 * kRows + wave * (16u * X);
+            q_issue(Qg + bh0 * head_elems, rb0);
+            if constexpr (kCarryKV) kv_issue(make_rsrc(Kg + bh0 * head_elems, head_bytes), make_rsrc(Vg + bh0 * head_elems, head_bytes));
+            constexpr unsigned es0 = kOutF32 ? 4u : 2u;
+            const __amdgpu_buffer_rsrc_t ro0 =
+                make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh0 * head_elems * es0, (unsigned)(head_elems * es0));
+#pragma unroll
+            for (unsigned i = 0; i < kStores; ++i) {
+                u32x4 z = zero4u;
+                asm volatile("" : "+v"(z));
+                if constexpr (kOutF32) buf_store16(ro0, rb0 * D * 4u, z);
+                else buf_store8(ro0, rb0 * D * 2u, u32x2{z[0], z[1]});
+            }
+        }
+    }
+    for (unsigned bid = first_bid; bid < nwg; bid = kScan ? scan_next() : bid + gridDim.x) {
 #ifdef FA_RP16_STAMPS   // lab: 100 MHz timestamps of the item's phases, written over O[first row of the item][0..7] (fp32 out only)
     unsigned long long ts[8] = {};
 #define FA_STAMP(i) ts[i] = wall_clock64()
@@ -511,7 +542,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // (so_q, 1-h) -> s_nxt, the PV unit (so_v, 1-h) <- pk_prev.  so_nq / so_nv: slots of the NEXT step's units.
     auto step = [&](auto h_c, auto masked_c, auto fast_c, auto track_c, int tile, f32x4 (&s_cur)[X][2], f32x4 (&s_nxt)[X][2],
                     u32x4 (&pk_prev)[X], u32x4 (&pk_cur)[X], unsigned so_q, unsigned so_v, unsigned so_nq, unsigned so_nv,
-                    unsigned so_land) __attribute__((always_inline)) {
+                    unsigned so_land, auto set_c) __attribute__((always_inline)) {
+        u32x4 (&k_land)[kLoads] = decltype(set_c)::value == 0 ? kst : kst2;   // the staging registers this step lands (h = 1)
+        u32x4 (&v_land)[kLoads] = decltype(set_c)::value == 0 ? vst : vst2;
         constexpr int h = decltype(h_c)::value, ho = 1 - h;
         constexpr bool kFast = decltype(fast_c)::value;
         if constexpr (decltype(masked_c)::value) mask_unit(tile, h, s_cur);
@@ -583,7 +616,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         auto fin_pair = [&](auto jc) {
             constexpr int j = decltype(jc)::value, x = j >> 2, kbl = (j >> 1) & 1, e = 2 * (j & 1);
             unsigned w = T::pack2(s_cur[x][kbl][e], s_cur[x][kbl][e + 1]);
-            if constexpr (FA_RP16_VSPLIT != 0) asm volatile("" : "+v"(w));
+            if constexpr (kVSplit) asm volatile("" : "+v"(w));
             pk_cur[x][2 * kbl + (j & 1)] = w;
             if constexpr (FA_RP16_SUMMFMA) {
             } else if constexpr (T::kSumRounded) {
@@ -615,6 +648,9 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             if constexpr ((f & 1) == 0) {
                 constexpr int kbl = (f >> 1) / kKS, ks = (f >> 1) % kKS;
                 using MQ = std::conditional_t<kCvtK && kFast, Mx<F16>, M>;
+                // (kWv == 4, one wave per SIMD: the allocator keeps these accumulators in the accumulator half of the file and copies
+                // every score out with a v_accvgpr_read -- 64 per tile.  Spelling the instruction out with the scores in architectural
+                // registers and Q in the accumulator half was tried: it then copies Q IN per use instead and spills; left as is.)
                 s_nxt[x][kbl] = MQ::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
             } else {
                 constexpr int db = f >> 1;
@@ -633,8 +669,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             if constexpr (h == 1 && i == kLandSlot && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
-                    lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
-                    lds_write16(smem, so_land + v_lds[p], vst[p]);
+                    lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(k_land[p]) : k_land[p]);
+                    lds_write16(smem, so_land + v_lds[p], v_land[p]);
                 }
             }
             issue_mfma(ic);
@@ -649,7 +685,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
             }
             constexpr int kPer = kSlots / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
-            if constexpr (FA_RP16_VSPLIT != 0 && (FA_RP16_ABL & 2) == 0) {
+            if constexpr (kVSplit && (FA_RP16_ABL & 2) == 0) {
                 // the pair-step's instructions one by one behind consecutive matrix instructions: a v_exp (or v_cvt_pk) of ~8 issue
                 // cycles fits in the shadow of the 16-cycle matrix instruction in front of it, three in a row do not
                 constexpr int j = i / kPer, sub = i % kPer;
@@ -691,23 +727,27 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             l_part[x] = 0.0f;
             ls[x][0] = ls[x][1] = 0.0f;
             lacc[x] = zero4;
-            pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of ring slot 3
+            pkB[x] = zero4u;   // "P(-1)" = 0 against the zeroed V of the ring's last slot
         }
         // ---- prologue: tiles 0 and 1 -> slots 0 and 1; V of slot 3 ("tile -1") zeroed ----
         if constexpr (kDma) {
 #pragma unroll
-            for (int p = 0; p < kLoads; ++p) lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
+            for (int p = 0; p < kLoads; ++p) lds_write16(smem, kRingMask * kSlotBytes + v_lds[p], zero4u);
             dma_tile(rk, rv, 0u, 0u);
             dma_tile(rk, rv, kTile, kSlotBytes);
         } else {   // tiles 0 and 1 -> LDS; tile 2 stays in the staging registers until iteration 0 lands it
             if constexpr (!kPre) kv_issue(rk, rv);
 #pragma unroll
             for (int p = 0; p < kLoads; ++p) {
-                lds_write16(smem, 3u * kSlotBytes + v_lds[p], zero4u);
+                lds_write16(smem, kRingMask * kSlotBytes + v_lds[p], zero4u);
                 lds_write16(smem, k_lds[p], (kCvtK && kFast) ? k_to_f16(pfk[0][p]) : pfk[0][p]);
                 lds_write16(smem, v_lds[p], pfv[0][p]);
                 lds_write16(smem, kSlotBytes + k_lds[p], (kCvtK && kFast) ? k_to_f16(pfk[1][p]) : pfk[1][p]);
                 lds_write16(smem, kSlotBytes + v_lds[p], pfv[1][p]);
+                if constexpr (kPair) {   // tile 2 as well: an iteration starts with the tiles up to two ahead of it in LDS
+                    lds_write16(smem, 2u * kSlotBytes + k_lds[p], (kCvtK && kFast) ? k_to_f16(kst[p]) : kst[p]);
+                    lds_write16(smem, 2u * kSlotBytes + v_lds[p], vst[p]);
+                }
             }
         }
         __syncthreads();
@@ -776,36 +816,17 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             }
         }
         // the first kAhead fragments of the first step: K(tile 0, half 1), V("tile -1")
-        sfor<kAhead>([&](auto fc) { read_frag(fc, 0u, 1, 3u * kSlotBytes, 1); });
+        sfor<kAhead>([&](auto fc) { read_frag(fc, 0u, 1, kRingMask * kSlotBytes, 1); });
 
         // phase_c: j & 3 when the caller knows it at compile time (the unrolled steady state: ring slot offsets become
         // immediates of the LDS instructions instead of one v_add per fragment read), -1 otherwise
         // req_c: request tile j+2 at the top (not in iteration 0 of the non-DMA path: the prologue already has it in flight)
-        auto tile_iter = [&](int j, auto masked_c, auto phase_c, auto req_c) __attribute__((always_inline)) {
-            constexpr int ph = decltype(phase_c)::value;
-            const unsigned jj = ph >= 0 ? (unsigned)ph : (unsigned)j;
-            const unsigned so_m1 = ((jj + 3u) & 3u) * kSlotBytes, so_0 = (jj & 3u) * kSlotBytes;
-            const unsigned so_p1 = ((jj + 1u) & 3u) * kSlotBytes, so_p2 = ((jj + 2u) & 3u) * kSlotBytes;
-            // tile j+2: tiles past the end read zeros through the buffer bounds into a free slot
-            if constexpr ((FA_RP16_ABL & 8) != 0 || !decltype(req_c)::value) {
-            } else if constexpr (kDma) {
-                dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_p2);   // the barrier below waits for it (vmcnt) and publishes it
-            } else {
-#pragma unroll
-                for (int p = 0; p < kLoads; ++p) {
-                    kst[p] = buf_load16(rk, (unsigned)(j + 2) * kTile + st_goff[p]);
-                    vst[p] = buf_load16(rv, (unsigned)(j + 2) * kTile + sv_goff[p]);
-                }
-            }
-            //   h 0: softmax (j,0);  QK^T (j,1);    PV (j-1,1);  next step: QK^T (j+1,0), PV (j,0)
-            //   h 1: softmax (j,1);  QK^T (j+1,0);  PV (j,0);    next step: QK^T (j+1,1), PV (j,1)
-            step(c0{}, masked_c, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p2);
-            step(c1{}, masked_c, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p2);
+        auto tile_barrier = [&]() __attribute__((always_inline)) {
             if constexpr ((FA_RP16_ABL & 16) != 0) {
             } else if constexpr (FA_RP16_RAWBAR != 0 && !kDma && kLdsAfterLand <= 15) {
-                // The barrier publishes this wave's ds_writes of tile j+2 (first read one iteration later) and orders the ring's
-                // reuse; it does not need the fragment reads issued since (LDS operations of a wave complete in order: once at
-                // most kLdsAfterLand are outstanding, the writes are done).  __syncthreads() would wait for all of them
+                // The barrier publishes this wave's ds_writes of the landed tile (first read at least one iteration later) and orders
+                // the ring's reuse; it does not need the fragment reads issued since (LDS operations of a wave complete in order: once
+                // at most kLdsAfterLand are outstanding, the writes are done).  __syncthreads() would wait for all of them
                 // (s_waitcnt lgkmcnt(0)): the latency of the last read, exposed once per tile.
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(kLdsAfterLand) : "memory");
@@ -815,22 +836,79 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 __syncthreads();
             }
         };
+        auto tile_iter = [&](int j, auto masked_c, auto phase_c, auto req_c) __attribute__((always_inline)) {
+            constexpr int ph = decltype(phase_c)::value;
+            const unsigned jj = ph >= 0 ? (unsigned)ph : (unsigned)j;
+            const unsigned so_m1 = ((jj + kRingMask) & kRingMask) * kSlotBytes, so_0 = (jj & kRingMask) * kSlotBytes;
+            const unsigned so_p1 = ((jj + 1u) & kRingMask) * kSlotBytes, so_ld = ((jj + (unsigned)kLook) & kRingMask) * kSlotBytes;
+            // tile j + kLook: tiles past the end read zeros through the buffer bounds into a free slot
+            if constexpr ((FA_RP16_ABL & 8) != 0 || !decltype(req_c)::value) {
+            } else if constexpr (kDma) {
+                dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_ld);   // the barrier below waits for it (vmcnt) and publishes it
+            } else {
+#pragma unroll
+                for (int p = 0; p < kLoads; ++p) {
+                    kst[p] = buf_load16(rk, (unsigned)(j + kLook) * kTile + st_goff[p]);
+                    vst[p] = buf_load16(rv, (unsigned)(j + kLook) * kTile + sv_goff[p]);
+                }
+            }
+            //   h 0: softmax (j,0);  QK^T (j,1);    PV (j-1,1);  next step: QK^T (j+1,0), PV (j,0)
+            //   h 1: softmax (j,1);  QK^T (j+1,0);  PV (j,0);    next step: QK^T (j+1,1), PV (j,1)
+            step(c0{}, masked_c, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_ld, c0{});
+            step(c1{}, masked_c, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_ld, c0{});
+            tile_barrier();
+        };
+        // kPair: tiles j and j+1 in one iteration: tiles j+3 and j+4 requested at the top and landed in the second step of each tile,
+        // one barrier behind both (the iteration starts with the tiles up to j+2 in LDS: the last step reads K of tile j+2)
+        auto pair_iter = [&](int j) __attribute__((always_inline)) {
+            const unsigned jj = (unsigned)j;
+            const unsigned so_m1 = ((jj + kRingMask) & kRingMask) * kSlotBytes, so_0 = (jj & kRingMask) * kSlotBytes;
+            const unsigned so_p1 = ((jj + 1u) & kRingMask) * kSlotBytes, so_p2 = ((jj + 2u) & kRingMask) * kSlotBytes;
+            const unsigned so_p3 = ((jj + 3u) & kRingMask) * kSlotBytes, so_p4 = ((jj + 4u) & kRingMask) * kSlotBytes;
+            if constexpr ((FA_RP16_ABL & 8) == 0) {
+#pragma unroll
+                for (int p = 0; p < kLoads; ++p) {
+                    kst[p] = buf_load16(rk, (unsigned)(j + 3) * kTile + st_goff[p]);
+                    vst[p] = buf_load16(rv, (unsigned)(j + 3) * kTile + sv_goff[p]);
+                    kst2[p] = buf_load16(rk, (unsigned)(j + 4) * kTile + st_goff[p]);
+                    vst2[p] = buf_load16(rv, (unsigned)(j + 4) * kTile + sv_goff[p]);
+                }
+            }
+            step(c0{}, no, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p3, c0{});
+            step(c1{}, no, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p3, c0{});
+            step(c0{}, no, fast_c, track_c, j + 1, sA, sB, pkB, pkA, so_p1, so_0, so_p2, so_p1, so_p4, c1{});
+            step(c1{}, no, fast_c, track_c, j + 1, sB, sA, pkA, pkB, so_p2, so_p1, so_p2, so_p1, so_p4, c1{});
+            tile_barrier();
+        };
         if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(3);
         using dyn = std::integral_constant<int, -1>;
-        const std::integral_constant<bool, kDma> req0{};   // iteration 0 only requests on the DMA path
+        // iteration 0 of the one-tile-per-iteration form requests nothing unless staging is by DMA: the prologue has tile 2 in flight
+        const std::integral_constant<bool, kDma || kPair> req0{};
         // returns true when the pass was given up on a workgroup vote: fp16 weights of the exact optimistic pass overflowed (the
         // matrix-pipe row sums are complete in every lane, so the look costs a compare per block and a vote every kCheckEvery tiles)
         auto full_tiles = [&](int nfull) __attribute__((always_inline)) -> bool {
+            constexpr bool kLook4Overflow = kMode == 1 && T::id == 0 && FA_RP16_SUMMFMA && FA_RP16_ABL == 0;
+            auto overflowed = [&]() -> bool {
+                bool over = false;
+#pragma unroll
+                for (int x = 0; x < X; ++x) over = over || !(lacc[x][0] < lim);
+                return __syncthreads_or(over ? 1 : 0) != 0;
+            };
             int j = 0;
+            if constexpr (kPair) {
+                for (; j + 1 < nfull; j += 2) {
+                    pair_iter(j);
+                    if constexpr (kLook4Overflow) { if (((j + 2) % kCheckEvery) == 0 && j + 2 < nfull && overflowed()) return true; }
+                }
+                if (j < nfull) tile_iter(j, no, dyn{}, yes);
+                return false;
+            }
             if (nfull > 0) { tile_iter(0, no, dyn{}, req0); j = 1; }
-            if constexpr (kMode == 1 && T::id == 0 && FA_RP16_SUMMFMA && FA_RP16_ABL == 0) {
+            if constexpr (kLook4Overflow) {
                 while (j < nfull) {
                     const int je = min(nfull, j + kCheckEvery);
                     for (; j < je; ++j) tile_iter(j, no, dyn{}, yes);
-                    bool over = false;
-#pragma unroll
-                    for (int x = 0; x < X; ++x) over = over || !(lacc[x][0] < lim);
-                    if (j < nfull && __syncthreads_or(over ? 1 : 0)) return true;
+                    if (j < nfull && overflowed()) return true;
                 }
             } else {
                 for (; j < nfull; ++j) tile_iter(j, no, dyn{}, yes);
@@ -852,7 +930,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(4);
         // ---- epilogue: O^T += V(last tile, half 1)^T.P^T ----
         {
-            const unsigned so = ((unsigned)(nt - 1) & 3u) * kSlotBytes;
+            const unsigned so = ((unsigned)(nt - 1) & kRingMask) * kSlotBytes;
 #pragma unroll
             for (int db = 0; db < kDB; ++db) {
                 const u32x4 vf = read_vf(so, 1, db);
@@ -874,12 +952,16 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // an optimistic pass' row sum: complete in every lane when it came from the matrix pipe
     auto row_sum = [&](int x) -> float { return FA_RP16_SUMMFMA ? lacc[x][0] : across_sum(l_part[x]); };
     if constexpr (!kPrefetch) q_issue(Qg + bh * head_elems, q_row0 - c16);   // else: requested by the item before (next_in)
-    else if constexpr (!kCarryKV) kv_issue(rk, rv);   // tiles 0..2 on their way before Q is waited for
+    else {
+        if constexpr (kScan) { if (!q_pending) q_issue(Qg + bh * head_elems, q_row0 - c16); }   // (first block of a later list batch)
+        if constexpr (!kCarryKV) kv_issue(rk, rv);   // tiles 0..2 on their way before Q is waited for
+    }
     const std::integral_constant<bool, kPrefetch> pre_c{};
     // qf, pfk/pfv, kst/vst <- the next item's raw Q rows and K/V tiles 0..2 (called between the last pass and the stores)
     auto next_in = [&]() __attribute__((always_inline)) {
         if constexpr (kPrefetch) {
-            const unsigned nbid = bid + gridDim.x;
+            const unsigned nbid = kScan ? scan_peek() : bid + gridDim.x;
+            if constexpr (kScan) q_pending = nbid < nwg;
             if (nbid < nwg) {
                 unsigned bh_n, qb_n;
                 locate(nbid, bh_n, qb_n);
@@ -911,7 +993,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             l_row[x] = row_sum(x);
             // causal: a row only has row+1 keys to add up
             const float lo_x = (kCausal && T::id == 0) ? (float)min((unsigned)n_here, q_row0 + 16u * x + 1u) * 0x1p-16f : lo;
-            bad = bad || ((FA_RP16_GATES & 1) && !(l_row[x] < lim)) || ((FA_RP16_GATES & 2) && !(l_row[x] >= lo_x)) ||
+            // upper gate: 60000 for BOTH input types.  For bf16 the weights themselves would hold far more (lim = 2^96), but a row
+            // sum beyond 2^16 means logits more than 16 above a reference that is itself up to kFoldMax in magnitude, and the
+            // rounding of Q' (|logit| 2^-11 per logit) then moves the ratio of two comparable dominant weights by up to ~0.5 %
+            bad = bad || ((FA_RP16_GATES & 1) && !(l_row[x] < 60000.0f)) || ((FA_RP16_GATES & 2) && !(l_row[x] >= lo_x)) ||
                   ((FA_RP16_GATES & 4) && !(fabsf(m_ref[x]) <= kFoldMax));
         }
         bad = bad || gave_up || ((FA_RP16_GATES & 8) && q_bad != 0) || !(k_amax <= 65504.0f);
@@ -952,7 +1037,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         if constexpr (kSplitTrack) {
             redo = true;
         } else {
-            run(std::integral_constant<int, 2>{}, no);
+            if constexpr (kScan) run(std::integral_constant<int, 2>{}, pre_c);   // (its K/V tiles 0..2 are on their way already)
+            else run(std::integral_constant<int, 2>{}, no);
 #pragma unroll
             for (int x = 0; x < X; ++x) l_row[x] = row_sum(x);
             __syncthreads();   // the next item's prologue writes the ring: every wave is past this pass' last LDS read
@@ -1028,19 +1114,20 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false>
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, int kWv = 8>
 static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
     using namespace rp16;
-    constexpr int lds_bytes = 4 * 2 * kBlockN * D * 2;   // ring of four [K tile][V tile] slots
+    constexpr int kW = kWv;
+    constexpr int lds_bytes = (pair_tiles(D, X, kDma) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring of four (eight) [K tile][V tile] slots
     constexpr int kRows = 16 * X * kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const long long cap = device_cus();
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma, kCausal>;
+    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma, kCausal, false, kWv>;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
     if (attr != hipSuccess) return attr;
     FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
@@ -1050,7 +1137,8 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     if constexpr (!kDma && 16 * X * (D / 64) >= 64) {
         // full-width waves: the redo kernel for the row blocks whose optimistic passes failed (see kScan): half-width waves,
         // running-max pass only; with nothing marked it ends after one look at the marker words
-        constexpr int X2 = X / 2, kRows2 = 16 * X2 * kW, lds2 = lds_bytes + 4 * (1 + 64 * kW);
+        constexpr int kW2 = 8, X2 = X * kW / (2 * kW2), kRows2 = 16 * X2 * kW2;
+        constexpr int lds2 = (pair_tiles(D, X2, false) ? 8 : 4) * 2 * kBlockN * D * 2 + 4 * (1 + 64 * kW2);   // (half this kernel's row block, on eight waves)
         const int nqb2 = (N + kRows2 - 1) / kRows2;
         const long long nwg2 = (long long)BH * nqb2;
         if (nwg2 > 0x7FFFFFFFll) return hipErrorInvalidValue;
@@ -1058,7 +1146,8 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
         auto kern2 = fa_fwd_rp16_kernel<T, D, X2, kOutF32, false, false, kCausal, true>;
         const hipError_t attr2 = ensure_dyn_lds(reinterpret_cast<const void*>(kern2), lds2);
         if (attr2 != hipSuccess) return attr2;
-        FA_LAUNCH(kern2, dim3(grid2), dim3(64 * kW), lds2, stream,
+        static_assert(2 * kRows2 == kRows, "the redo kernel's row block is half of this kernel's");
+        FA_LAUNCH(kern2, dim3(grid2), dim3(64 * kW2), lds2, stream,
                   static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb2,
                   scale * kLog2e, (unsigned)nwg2);
     }
@@ -1067,11 +1156,11 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
 
 // One (D, X, staging, mask) family of the pipeline: its (input type, output type, folded-first) instantiations.  The families
 // live in translation units of their own (fa_fwd_rp16_{d64,d64n,d128,c}.hip) so that they compile side by side.
-template <int D, int X, bool kDma, bool kCausal>
+template <int D, int X, bool kDma, bool kCausal, int kWv = 8>
 static hipError_t rp16_family(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale,
                               int in_dtype, int out_dtype, bool fold, hipStream_t stream)
 {
-#define RP16_L(T, OUT, FOLD) launch_rp16<T, D, X, OUT, FOLD, kDma, kCausal>(Q, K, V, O, BH, N, scale, stream)
+#define RP16_L(T, OUT, FOLD) launch_rp16<T, D, X, OUT, FOLD, kDma, kCausal, kWv>(Q, K, V, O, BH, N, scale, stream)
     if (in_dtype == 0) {
         if (fold) return out_dtype == 0 ? RP16_L(F16, true, true) : RP16_L(F16, false, true);
         return out_dtype == 0 ? RP16_L(F16, true, false) : RP16_L(F16, false, false);

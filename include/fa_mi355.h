@@ -45,6 +45,7 @@ extern "C" {
 #define FA_ALGO_RP16_FOLD_HALF 26 /* RP16_FOLD on half-width waves (256-row workgroups at D = 64, 128-row at D = 128): grids too
                                      small to cover the device with the full-width ones */
 #define FA_ALGO_RP16_FOLD_QUARTER 27 /* ... on quarter-width waves (128-row workgroups), D = 64 */
+#define FA_ALGO_RP16_FOLD_1W   28 /* RP16_FOLD at D = 128 with ONE wave per SIMD: four 64-row waves per 256-row workgroup, 512 registers each */
 /* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
  * A/B kernels that AUTO never selects. */
 #define FA_ALGO_W64            13 /* round 1's default for bf16: 64 query rows per wave, phase-ordered stream on 32x32x16, packed fp32 */

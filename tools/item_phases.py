@@ -2,7 +2,8 @@
 """Where an item of the persistent pipeline spends its time outside the tile loop: in-kernel 100 MHz stamps of a
 -DFA_RP16_STAMPS build (tools/build_variant.sh stfin "-DFA_RP16_STAMPS"; the stamps overwrite O[first row of the
 item][0..7], so such a build is for this tool only).  B8 H16 N4096 d64 fp16, mean over the 256 items of each round.
-    python tools/item_phases.py stnopf stfin      (names of gpurun_variants/lib_<name>.so)"""
+    python tools/item_phases.py stnopf stfin      (names of gpurun_variants/lib_<name>.so)
+    FA_PHASES_SHAPE=4,8,1024,64,27,128 python tools/item_phases.py stamps      (B,H,N,d,algo,rows per item: BASELINE config 3)"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +14,7 @@ import torch  # noqa: E402
 from flashattention_kernel_project_amd import capi  # noqa: E402
 
 capi._share_torch_hip_runtime()
-B, H, N, d = 8, 16, 4096, 64
+B, H, N, d, ALGO, ROWS = (int(x) for x in os.environ.get("FA_PHASES_SHAPE", "8,16,4096,64,24,512").split(","))
 g = torch.Generator(device="cuda").manual_seed(0)
 q, k, v = (torch.randn(B, H, N, d, generator=g, device="cuda").half() for _ in range(3))
 o = torch.empty(B, H, N, d, device="cuda", dtype=torch.float32)
@@ -24,15 +25,15 @@ for name in sys.argv[1:]:
     L = C.CDLL(os.path.join(ROOT, "gpurun_variants", f"lib_{name}.so"))
     L.fa_forward_ex.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3 + [C.c_void_p]
     for _ in range(200):
-        rc = L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, N, d, 0.125, 0, 0, 24, st)
+        rc = L.fa_forward_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), B, H, N, d, 1.0 / d ** 0.5, 0, 0, ALGO, st)
         assert rc == 0
     torch.cuda.synchronize()
-    s = o.view(B * H, N // 512, 512, d)[:, :, 0, :8].reshape(-1, 8).cpu()   # one row of stamps per item
+    s = o.view(B * H, N // ROWS, ROWS, d)[:, :, 0, :8].reshape(-1, 8).cpu()   # one row of stamps per item
     t0 = s[:, 0]
     start = ((t0 - t0.min()) % (1 << 24)) / 100.0
     order = torch.argsort(start)
     s, start = s[order], start[order]
-    for r in range(4):
+    for r in range(min(4, (s.shape[0] + 255) // 256)):
         seg, beg = s[r * 256:(r + 1) * 256], start[r * 256:(r + 1) * 256]
         print(f"{name:8s} round {r}: item start {float(beg.mean()):7.1f} (+-{float(beg.std()):.1f})  " +
               "  ".join(f"{n} {float(seg[:, i + 1].mean()) / 100:.2f}" for i, n in enumerate(names)), flush=True)
