@@ -356,22 +356,25 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         unsigned* list = reinterpret_cast<unsigned*>(smem + kRingSlots * kSlotBytes);   // [0] = count, [1 ..] = block ids
         while (scan_i == scan_n) {
             if (blockIdx.x + scan_base * gridDim.x >= nwg) return nwg;
-            __syncthreads();   // (every wave is done with the previous batch's list and with the ring)
-            if (tid == 0) list[0] = 0u;
-            __syncthreads();
             const unsigned long long b = (unsigned long long)blockIdx.x + (unsigned long long)(scan_base + tid) * gridDim.x;
+            bool marked = false;
             if (b < nwg) {
                 unsigned bh_, qb_;
                 locate((unsigned)b, bh_, qb_);
                 constexpr unsigned es_ = kOutF32 ? 4u : 2u;
                 const unsigned* w0 = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(Og) +
                                                                        ((size_t)bh_ * head_elems + (size_t)qb_ * kRows * D) * es_);
-                if (*w0 == kMarker) list[1u + atomicAdd(&list[0], 1u)] = (unsigned)b;
+                marked = *w0 == kMarker;
             }
+            scan_i = scan_n = 0;
+            scan_base += kScanBatch;
+            // (the vote is also the barrier behind which every wave is done with the previous batch's list and with the ring)
+            if (!__syncthreads_or(marked ? 1 : 0)) continue;   // the common case: nothing to do in this batch
+            if (tid == 0) list[0] = 0u;
+            __syncthreads();
+            if (marked) list[1u + atomicAdd(&list[0], 1u)] = (unsigned)b;
             __syncthreads();
             scan_n = __builtin_amdgcn_readfirstlane(list[0]);
-            scan_i = 0;
-            scan_base += kScanBatch;
         }
         const unsigned r = __builtin_amdgcn_readfirstlane(list[1u + scan_i]);
         ++scan_i;

@@ -93,7 +93,9 @@ def main():
         if not (err <= tol) or not torch.isfinite(got).all():
             fails += 1
             print(f"FAIL err={err:.3e} tol={tol:.0e}: {desc}", flush=True)
-    print(f"fuzz: seed {args.seed} library {os.path.basename(__import__("flashattention_kernel_project_amd.capi", fromlist=["x"]).LIB_PATH)} ({fa.version()}): {cases} cases in {time.time() - t0:.0f} s, {fails} failures, worst max-abs {worst:.3e}", flush=True)
+    from flashattention_kernel_project_amd import capi as _capi
+    libname = os.path.basename(_capi.LIB_PATH)
+    print(f"fuzz: seed {args.seed} library {libname} ({fa.version()}): {cases} cases in {time.time() - t0:.0f} s, {fails} failures, worst max-abs {worst:.3e}", flush=True)
     sys.exit(1 if fails else 0)
 
 
