@@ -18,7 +18,7 @@
 // family checks the first --check-heads (b,h) heads (all of them when the problem is small).
 // `--dump FILE` writes O of device 0 for external comparison.
 //
-//   bench/fa_bench --B 8 --H 16 --N 4096 --d 64 --dtype f16 --iters 50 --warmup 10 [--gpus 8] [--check]
+//   bench/fa_bench --B 8 --H 16 --N 4096 --d 64 --dtype f16 --iters 50 --warmup 10 [--gpus 8 [--one-device]] [--check]
 //   bench/fa_bench --family s16 --B 1024 --N 128 [--check]  (16x16 streaming family; N = seq_len)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -51,6 +51,7 @@ namespace {
 struct Args {
     std::string family = "general", dtype = "f16", out = "f32", dump, checker;
     int B = 8, H = 16, N = 4096, d = 64, iters = 50, warmup = 10, gpus = 1, algo = 0, check_heads = 0;
+    bool one_device = false;   // --one-device: rehearse --gpus G on a one-GPU box (every shard's thread and stream on device 0)
     bool check = false;
     uint64_t seed = 42;
 };
@@ -293,6 +294,7 @@ int main(int argc, char** argv)
         else if (is("--checker")) a.checker = argv[++i];
         else if (is("--check-heads")) a.check_heads = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--check")) a.check = true;
+        else if (!std::strcmp(argv[i], "--one-device")) a.one_device = true;
         else { std::fprintf(stderr, "unknown or incomplete flag %s\n", argv[i]); return 2; }
     }
     if (a.checker.empty()) a.checker = default_checker(argv[0]);
@@ -301,12 +303,12 @@ int main(int argc, char** argv)
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { std::fprintf(stderr, "no GPU\n"); return 1; }
-    const int G = std::max(1, std::min(a.gpus, ndev));
+    const int G = std::max(1, a.one_device ? a.gpus : std::min(a.gpus, ndev));
     const int BH = a.B * a.H;
     std::vector<Shard> sh(G);
     for (int g = 0; g < G; ++g) {   // contiguous split of the flattened (b,h) axis, sizes differ by <= 1
         const int q = BH / G, r = BH % G;
-        sh[g].dev = g;
+        sh[g].dev = a.one_device ? 0 : g;
         sh[g].bh0 = g * q + std::min(g, r);
         sh[g].bh1 = sh[g].bh0 + q + (g < r ? 1 : 0);
     }
@@ -320,7 +322,7 @@ int main(int argc, char** argv)
         if (s.rc) return s.rc;
         worst = std::max(worst, s.ms);
         const double fl = 4.0 * (s.bh1 - s.bh0) * (double)a.N * a.N * a.d;
-        std::printf("  gpu %d: (b,h) [%d,%d)  avg %.4f ms  %.2f TFLOPS\n", s.dev, s.bh0, s.bh1, s.ms, fl / (s.ms * 1e-3) / 1e12);
+        std::printf("  shard %d on gpu %d: (b,h) [%d,%d)  avg %.4f ms  %.2f TFLOPS\n", (int)(&s - &sh[0]), s.dev, s.bh0, s.bh1, s.ms, fl / (s.ms * 1e-3) / 1e12);
     }
     const double flops = 4.0 * BH * (double)a.N * a.N * a.d;                       // memprofile.cu:508
     const double bytes = 3.0 * BH * a.N * a.d * 2 + 1.0 * BH * a.N * a.d * (a.out == "f32" ? 4 : 2);  // memprofile.cu:518-520

@@ -858,6 +858,22 @@ def test_native_harness_check_step():
         assert "TFLOPS" in out.stdout
 
 
+def test_native_harness_two_shard_rehearsal():
+    """bench/fa_bench --gpus 2 --one-device: the native driver's multi-GPU mode (contiguous (b,h) shards, one host thread and
+    stream per shard, per-shard and aggregate TFLOP/s) rehearsed on ONE device; the shards tile the batch exactly."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bench", "fa_bench")
+    subprocess.check_call(["make", "-C", os.path.join(root, "bench")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, "--B", "3", "--H", "5", "--N", "512", "--d", "64", "--gpus", "2", "--one-device", "--iters", "5", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    shards = re.findall(r"shard (\d) on gpu (\d): \(b,h\) \[(\d+),(\d+)\)\s+avg ([0-9.]+) ms\s+([0-9.]+) TFLOPS", out.stdout)
+    assert [(int(a), int(b), int(c), int(d)) for (a, b, c, d, _, _) in shards] == [(0, 0, 0, 8), (1, 0, 8, 15)], out.stdout
+    assert all(float(t) > 0 for (*_, t) in shards) and re.search(r"gpus=2\s+[0-9.]+ ms\s+[0-9.]+ TFLOPS aggregate", out.stdout), out.stdout
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_causal_large_grid_item_order(fa, oracle, torch_cuda, fmt):
     """The causal pipeline alternates the direction of the query blocks between rounds of its persistent grid: with more
