@@ -14,7 +14,7 @@ OUT_F32, OUT_SAME = 0, 1
 ALGO_AUTO, ALGO_GENERIC, ALGO_TILED, ALGO_INTERLEAVED, ALGO_INTERLEAVED_2WG = 0, 1, 2, 5, 6
 ALGO_W64, ALGO_W64P, ALGO_W64X = 13, 14, 16
 ALGO_SK, ALGO_RP, ALGO_RP_FOLD, ALGO_RP16, ALGO_RP16_FOLD = 17, 21, 22, 23, 24
-ALGO_RP16_FOLD_HALF, ALGO_RP16_FOLD_QUARTER, ALGO_RP16_FOLD_1W = 26, 27, 28
+ALGO_RP16_FOLD_HALF, ALGO_RP16_FOLD_QUARTER, ALGO_RP16_FOLD_1W, ALGO_RP16_FOLD_KS2 = 26, 27, 28, 29
 
 # every symbol include/fa_mi355.h declares
 SYMBOLS = (

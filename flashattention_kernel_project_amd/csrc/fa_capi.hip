@@ -86,7 +86,7 @@ FA_EXPORT int fa_forward_ex(const void* Q, const void* K, const void* V, void* O
                   int in_dtype, int out_dtype, int algo, void* stream)
 {
     if (B <= 0 || H <= 0 || (long long)B * H > 0x7FFFFFFFll) return (int)hipErrorInvalidValue;
-    if (algo < FA_ALGO_AUTO || algo > 28) return (int)hipErrorInvalidValue;
+    if (algo < FA_ALGO_AUTO || algo > 29) return (int)hipErrorInvalidValue;
     if (out_dtype != FA_OUT_F32 && out_dtype != FA_OUT_SAME) return (int)hipErrorInvalidValue;
     return (int)fa::forward_dispatch(Q, K, V, O, B * H, N, d, scale, in_dtype, out_dtype, algo,
                                      static_cast<hipStream_t>(stream));

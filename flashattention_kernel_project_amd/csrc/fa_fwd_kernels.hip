@@ -513,6 +513,10 @@ int auto_algo(int BH, int N, int D, int in_dtype)
         const double cost = (double)((nwg + cus - 1) / cus) * rows / eff[w];
         if (w == 0 || cost < best_cost) { best = ids[w]; best_cost = cost; }
     }
+    // 128-row workgroups on long sequences: the same rows as 32-row waves on half the keys each (key split, 29) -- every LDS
+    // fragment feeds two matrix instructions; B1 H16 N2048 0.0268 vs 0.0280 ms, B2 H8 N4096 0.0821 vs 0.0882 (profiles/
+    // r03_cfg3_variants.txt); at N = 1024 it loses 2 %
+    if (best == 27 && D == 64 && N >= 2048 && N % 128 == 0) best = 29;
     return best;
 }
 
@@ -528,7 +532,7 @@ const char* algo_kernel_name(int algo, int D)
         case 16: return "fa::fa_fwd_w64x_kernel";
         case 21: case 22: return "fa::fa_fwd_rp_kernel";
 #endif
-        case 23: case 24: case 25: case 26: case 27: case 28: return "fa::fa_fwd_rp16_kernel";
+        case 23: case 24: case 25: case 26: case 27: case 28: case 29: return "fa::fa_fwd_rp16_kernel";
         default: return "";
     }
 }
@@ -549,6 +553,11 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     if (algo == 6) return il_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 4, stream);
     if (algo == 23) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 0, stream);
     if (algo == 24) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1, stream);
+    if (algo == 29) {   // 32-row waves, keys split over two groups of four waves per 128-row workgroup (d = 64); the split needs
+        if (D != 64) return hipErrorInvalidValue;   // whole tiles per group: other N run the 16-row waves (same workgroup size)
+        if (N % 128 != 0) return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1 | 8, stream);
+        return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1 | 4 | 16, stream);
+    }
     if (algo == 28) {   // d = 128 with one wave per SIMD (four 64-row waves, the whole register file each)
         if (D != 128) return hipErrorInvalidValue;
         return rp16_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, 1 | 12, stream);
@@ -571,7 +580,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     }
     if (algo == 14) return w64p_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
 #else
-    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo == 25 || algo > 28) return hipErrorInvalidValue;
+    if (algo == 3 || algo == 4 || (algo >= 7 && algo <= 22) || algo == 25 || algo > 29) return hipErrorInvalidValue;
 #endif
     if (algo == 3 || algo == 4 || (algo >= 9 && algo <= 12) || algo == 15) return hipErrorInvalidValue;   // ids of removed A/B kernels
     if (in_dtype == 0)

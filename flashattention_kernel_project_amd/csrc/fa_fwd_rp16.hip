@@ -10,6 +10,7 @@ namespace fa {
 RP16_FAMILY_DECL(rp16_d64x4);    // 64-row waves, 512-row workgroups (+ the half-width redo kernel)
 RP16_FAMILY_DECL(rp16_d64x2);    // 32-row waves
 RP16_FAMILY_DECL(rp16_d64x1);    // 16-row waves
+RP16_FAMILY_DECL(rp16_d64x2ks2); // 32-row waves, keys split over two groups of FOUR waves per 128-row workgroup (N % 128 == 0)
 RP16_FAMILY_DECL(rp16_d128x2);   // d = 128: 32-row waves, 256-row workgroups (+ redo kernel on 16-row waves)
 RP16_FAMILY_DECL(rp16_d128x1);
 RP16_FAMILY_DECL(rp16_d128x4w4); // d = 128, one wave per SIMD: four 64-row waves, 256-row workgroups, 512 registers per wave
@@ -22,6 +23,7 @@ hipError_t rp16_set_pass_ids_d64n(unsigned*);
 hipError_t rp16_set_pass_ids_d128(unsigned*);
 hipError_t rp16_set_pass_ids_c(unsigned*);
 hipError_t rp16_set_pass_ids_d128w(unsigned*);
+hipError_t rp16_set_pass_ids_d64ks(unsigned*);
 hipError_t rp16_set_pass_ids(unsigned* dev_ptr)
 {
     hipError_t e = rp16_set_pass_ids_d64(dev_ptr);
@@ -29,6 +31,7 @@ hipError_t rp16_set_pass_ids(unsigned* dev_ptr)
     if (e == hipSuccess) e = rp16_set_pass_ids_d128(dev_ptr);
     if (e == hipSuccess) e = rp16_set_pass_ids_c(dev_ptr);
     if (e == hipSuccess) e = rp16_set_pass_ids_d128w(dev_ptr);
+    if (e == hipSuccess) e = rp16_set_pass_ids_d64ks(dev_ptr);
     return e;
 }
 #endif
@@ -41,7 +44,7 @@ static bool rp16_shape_ok(int N, int D)
 }
 
 // fold: 1 = folded fast pass first, 0 = exact passes only; +2 = K/V staging by LDS-DMA (experimental build); bits 2-3: 1 = half-width
-// waves (32 rows at D = 64, 16 at D = 128), 2 = quarter-width (16 rows, D = 64), 3 = one wave per SIMD (64-row waves, D = 128)
+// waves (32 rows at D = 64, 16 at D = 128), 2 = quarter-width (16 rows, D = 64), 3 = one wave per SIMD (64-row waves, D = 128); +16 with 1: keys split over two groups of four 32-row waves (N % 128 == 0)
 hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
                          hipStream_t stream)
@@ -57,6 +60,7 @@ hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
         return narrow ? rp16_d128x1(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, f, stream)
                       : rp16_d128x2(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, f, stream);
     }
+    if (narrow == 1 && (fold & 16) && !dma) return rp16_d64x2ks2(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, f, stream);
     if (narrow) {   // small grids: the same pipeline on narrower waves
         if (dma || narrow > 2) return hipErrorInvalidValue;
         return narrow == 1 ? rp16_d64x2(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, f, stream)

@@ -143,15 +143,24 @@ static hipError_t rp16_set_pass_ids_tu(unsigned* dev_ptr) { return hipMemcpyToSy
 // CDNA4 guide documents for d = 128 (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD"), built here on this stream.
 // (kWv = 4 with 16-row waves at D = 64 -- 64-row workgroups, two per CU -- was measured for small grids and lost: 23.5 against
 // 16.9 us at B4 H8 N1024, every workgroup stages every tile of its head.)
-template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, bool kScan = false, int kWv = 8>
-__global__ __launch_bounds__(64 * kWv, kWv == 8 ? 2 : 1)
+// kKeySplit = 2 (small grids; 16-row waves, D = 64, N a multiple of 128): the workgroup is TWO groups of eight waves over the
+// same 128 query rows, group s running the whole algorithm -- its own LDS ring, its own reference, every pass -- over keys
+// [s N/2, (s+1) N/2); the votes and barriers are workgroup-wide (both groups run the same number of tiles), and group 1 hands
+// (O, l, m) to group 0 through LDS at the end, which merges with 2^(m_s - M) weights and stores.  A wave's chain of tiles
+// halves and four waves share a SIMD instead of two -- for grids where a workgroup per CU runs a handful of tiles and waits
+// on LDS latency and the barrier most of the time.
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, bool kScan = false, int kWv = 8,
+          int kKeySplit = 1>
+__global__ __launch_bounds__(64 * kWv * kKeySplit, kWv * kKeySplit / 4)
 void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restrict__ Kg,
                         const uint16_t* __restrict__ Vg, void* __restrict__ Og,
                         int N, int nqb, float scale_log2e, unsigned total_wg)
 {
     using namespace rp16;
     constexpr int kW = kWv;   // (hides rp16::kW, the default)
-    static_assert(kWv == 8 || (kWv == 4 && !kDma && !kScan), "waves per workgroup: 8, or 4 (one per SIMD)");
+    static_assert(kWv == 8 || (kWv == 4 && !kDma && !kScan), "waves per (key-split group of a) workgroup: 8 or 4");
+    static_assert(kKeySplit == 1 || (kKeySplit == 2 && ((kWv == 8 && X == 1) || (kWv == 4 && X == 2)) && D == 64 && !kDma && !kCausal && !kScan),
+                  "key split: 128-row workgroups at D = 64 (2 x 8 waves of 16 rows, or 2 x 4 waves of 32 rows)");
     using M = Mx<T>;
     using G = TileGeom<D>;
     // The folded pass multiplies Q'.K on the fp16 matrix instruction whatever the input type: Q' = fp16(Q * scale * log2 e)
@@ -192,19 +201,23 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr unsigned kRowB = D * 2;
     constexpr unsigned kTile = kBlockN * D * 2;
     constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
-    constexpr bool kPair = pair_tiles(D, X, kDma);
+    constexpr bool kPair = pair_tiles(D, X, kDma) && kKeySplit == 1;   // (two rings of eight slots do not fit)
     constexpr unsigned kRingSlots = kPair ? 8u : 4u, kRingMask = kRingSlots - 1u;
     constexpr int kLook = kPair ? 3 : 2;            // a tile is landed this many tiles ahead of the iteration that starts with it
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of four slots
-
-    const unsigned tid  = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];   // one ring of slots per key-split group
+    const unsigned grp = kKeySplit == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x / (64u * kW));
+    char* const smem = smem_all + grp * (kRingSlots * kSlotBytes);
+    const unsigned tid  = kKeySplit == 1 ? threadIdx.x : threadIdx.x % (64u * kW);   // within the group
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lane = tid & 63u;
     const unsigned c16 = lane & 15u, g = lane >> 4;
     const float c = fabsf(scale_log2e);
     const unsigned q_flip = scale_log2e < 0.0f ? 0x80008000u : 0u;
-    const int ntiles = (N + kBlockN - 1) / kBlockN;
-    const bool partial = (N % kBlockN) != 0;
+    const int Nkv = N / kKeySplit;                       // keys of this group (the host checked the divisibility)
+    const size_t kv_first = (size_t)grp * Nkv * D;       // its first K / V element inside a head
+    const unsigned kv_bytes = (unsigned)((size_t)Nkv * D * 2);
+    const int ntiles = (Nkv + kBlockN - 1) / kBlockN;
+    const bool partial = (Nkv % kBlockN) != 0;
 
     unsigned st_goff[kLoads], sv_goff[kLoads], k_lds[kLoads], v_lds[kLoads];
 #pragma unroll
@@ -407,7 +420,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             const __amdgpu_buffer_rsrc_t ro0 =
                 make_rsrc(reinterpret_cast<char*>(Og) + (size_t)bh0 * head_elems * es0, (unsigned)(head_elems * es0));
 #pragma unroll
-            for (unsigned i = 0; i < kStores; ++i) {
+            for (unsigned i = 0; i < (grp == 0u ? kStores : 0u); ++i) {   // (key-split group 1 never stores to O)
                 u32x4 z = zero4u;
                 asm volatile("" : "+v"(z));
                 if constexpr (kOutF32) buf_store16(ro0, rb0 * D * 4u, z);
@@ -430,8 +443,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     if constexpr (FA_RP16_TOP_BARRIER) { if (bid != blockIdx.x) __syncthreads(); }
     unsigned bh, qb;
     locate(bid, bh, qb);
-    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems, head_bytes);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems, head_bytes);
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems + kv_first, kv_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems + kv_first, kv_bytes);
     const unsigned q_row0 = qb * kRows + wave * (16u * X) + c16;   // row of block 0; block x is 16x rows further
     // causal: tiles [0, nt) with nt up to the diagonal of the workgroup's last (existing) row; tiles >= jc cross its row range
     const int nt = kCausal ? min(ntiles, (int)(min((unsigned)N - 1u, qb * kRows + kRows - 1u) / kBlockN) + 1) : ntiles;
@@ -533,7 +546,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int key = tile * kBlockN + 32 * h + 16 * kbl + 4 * (int)g + i;
-                    if (key >= N || (kCausal && (unsigned)key > q_row0 + 16u * x)) s[x][kbl][i] = -INFINITY;
+                    if (key >= Nkv || (kCausal && (unsigned)key > q_row0 + 16u * x)) s[x][kbl][i] = -INFINITY;
                 }
     };
     auto row_max = [&](const f32x4 (&s)[2]) -> float {   // this row's 32 keys of the unit, unscaled
@@ -795,7 +808,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     for (int sh = 1; sh < 16; sh <<= 1) e += row_ror(e, sh);
                     // (N through an opaque copy: hoisted out of the item loop, the product would be spilled around the tile
                     // loop and its reload -- s_waitcnt vmcnt(0) -- would sit behind whatever memory traffic is in flight)
-                    int n_here = N;
+                    int n_here = Nkv;
                     asm volatile("" : "+s"(n_here));
                     const float shift = __builtin_amdgcn_logf((float)n_here * e * (1.0f / (16.0f * X * 32.0f))) - kFoldAim;
                     mw += fminf(fmaxf(shift, -kFoldShiftMin), kFoldMax);
@@ -988,7 +1001,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         // fp16 weights: each subnormal one is off by at most 2^-25, N of them by N * 2^-25 in the worst case (2^-13 * sqrt(N)
         // typically), which stays below 2^-9 of the row sum; bf16 weights only must not vanish in fp32 (a row more than ~100
         // log2 units below its wave's reference: p = 0, l = 0)
-        int n_here = N;
+        int n_here = Nkv;
         asm volatile("" : "+s"(n_here));   // as above: no spilled constant behind the Q prefetch
         const float lo = T::id == 0 ? (float)n_here * 0x1p-16f : 0x1p-100f;
 #pragma unroll
@@ -1066,6 +1079,43 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
     }
 
+    if constexpr (kKeySplit == 2) {
+        // group 1 -> group 0: (O^T unnormalised, l, m) per lane through group 1's ring (both rings are idle: every wave is past
+        // its last fragment read once it is past this barrier); weights 2^(m_s - M)
+        float* const xch = reinterpret_cast<float*>(smem_all + kRingSlots * kSlotBytes) + tid;
+        constexpr unsigned kStride = 64u * kW;
+        __syncthreads();
+        if (grp == 1u) {
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+#pragma unroll
+                for (int db = 0; db < kDB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xch[((x * kDB + db) * 4 + i) * kStride] = o[x][db][i];
+                xch[(X * kDB * 4 + 2 * x) * kStride] = l_row[x];
+                xch[(X * kDB * 4 + 2 * x + 1) * kStride] = m_ref[x];
+            }
+        }
+        __syncthreads();
+        if (grp == 0u) {
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                const float l1 = xch[(X * kDB * 4 + 2 * x) * kStride], m1 = xch[(X * kDB * 4 + 2 * x + 1) * kStride];
+                const float mm = fmaxf(m_ref[x], m1);
+                const float a0 = fast_exp2(m_ref[x] - mm), a1 = fast_exp2(m1 - mm);
+#pragma unroll
+                for (int db = 0; db < kDB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[x][db][i] = o[x][db][i] * a0 + xch[((x * kDB + db) * 4 + i) * kStride] * a1;
+                l_row[x] = l_row[x] * a0 + l1 * a1;
+            }
+        }
+        __syncthreads();   // (group 1's next prologue writes the ring group 0 has just read)
+        if (grp == 1u) {
+            next_in();
+            continue;
+        }
+    }
     // normalise in place FIRST (no temporaries alive when the prefetch takes its registers), then the next item's loads, then
     // the stores straight from the accumulators
 #pragma unroll
@@ -1117,23 +1167,24 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }   // persistent loop over work items
 }
 
-template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, int kWv = 8>
+template <typename T, int D, int X, bool kOutF32, bool kFold, bool kDma = false, bool kCausal = false, int kWv = 8, int kKeySplit = 1>
 static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void* O,
                               int BH, int N, float scale, hipStream_t stream)
 {
     using namespace rp16;
     constexpr int kW = kWv;
-    constexpr int lds_bytes = (pair_tiles(D, X, kDma) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring of four (eight) [K tile][V tile] slots
+    constexpr int lds_bytes = kKeySplit * ((pair_tiles(D, X, kDma) && kKeySplit == 1) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring(s) of four (eight) [K tile][V tile] slots
+    if (kKeySplit > 1 && N % (kBlockN * kKeySplit) != 0) return hipErrorInvalidValue;
     constexpr int kRows = 16 * X * kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
     if (nwg > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const long long cap = device_cus();
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
-    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma, kCausal, false, kWv>;
+    auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma, kCausal, false, kWv, kKeySplit>;
     const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
     if (attr != hipSuccess) return attr;
-    FA_LAUNCH(kern, dim3(grid), dim3(64 * kW), lds_bytes, stream,
+    FA_LAUNCH(kern, dim3(grid), dim3(64 * kW * kKeySplit), lds_bytes, stream,
               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb,
               scale * kLog2e, (unsigned)nwg);
     if (launch_status() != hipSuccess) return launch_status();
@@ -1159,11 +1210,11 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
 
 // One (D, X, staging, mask) family of the pipeline: its (input type, output type, folded-first) instantiations.  The families
 // live in translation units of their own (fa_fwd_rp16_{d64,d64n,d128,c}.hip) so that they compile side by side.
-template <int D, int X, bool kDma, bool kCausal, int kWv = 8>
+template <int D, int X, bool kDma, bool kCausal, int kWv = 8, int kKeySplit = 1>
 static hipError_t rp16_family(const void* Q, const void* K, const void* V, void* O, int BH, int N, float scale,
                               int in_dtype, int out_dtype, bool fold, hipStream_t stream)
 {
-#define RP16_L(T, OUT, FOLD) launch_rp16<T, D, X, OUT, FOLD, kDma, kCausal, kWv>(Q, K, V, O, BH, N, scale, stream)
+#define RP16_L(T, OUT, FOLD) launch_rp16<T, D, X, OUT, FOLD, kDma, kCausal, kWv, kKeySplit>(Q, K, V, O, BH, N, scale, stream)
     if (in_dtype == 0) {
         if (fold) return out_dtype == 0 ? RP16_L(F16, true, true) : RP16_L(F16, false, true);
         return out_dtype == 0 ? RP16_L(F16, true, false) : RP16_L(F16, false, false);

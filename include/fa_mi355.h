@@ -31,7 +31,7 @@ extern "C" {
 
 /* Kernel selection for fa_forward_ex().  Ids present in the product library: */
 #define FA_ALGO_AUTO            0 /* d=64, N > 256 and d=128: RP16_FOLD on the widest waves whose grid still covers the device
-                                     (24, else _HALF 26, else _QUARTER 27, by rounds x rows / efficiency); d=64, N <= 256:
+                                     (24, else _HALF 26, else _QUARTER 27 / _KS2 29, by rounds x rows / efficiency); d=64, N <= 256:
                                      INTERLEAVED / _2WG; else GENERIC -- fa_selected_algo() */
 #define FA_ALGO_GENERIC         1 /* single 16x16 MFMA fragment per wave, any D % 16 == 0, D <= 256 */
 #define FA_ALGO_TILED           2 /* LDS-staged 256-row workgroups, QK^T -> softmax -> PV per tile, D in {64,128} */
@@ -45,6 +45,8 @@ extern "C" {
 #define FA_ALGO_RP16_FOLD_HALF 26 /* RP16_FOLD on half-width waves (256-row workgroups at D = 64, 128-row at D = 128): grids too
                                      small to cover the device with the full-width ones */
 #define FA_ALGO_RP16_FOLD_QUARTER 27 /* ... on quarter-width waves (128-row workgroups), D = 64 */
+#define FA_ALGO_RP16_FOLD_KS2  29 /* RP16_FOLD, D = 64, 128-row workgroups: two groups of four 32-row waves, each on half the keys, merged through LDS
+                                     (N % 128 == 0; other N run _QUARTER); AUTO for few heads and N >= 2048 */
 #define FA_ALGO_RP16_FOLD_1W   28 /* RP16_FOLD at D = 128 with ONE wave per SIMD: four 64-row waves per 256-row workgroup, 512 registers each */
 /* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
  * A/B kernels that AUTO never selects. */

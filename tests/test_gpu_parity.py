@@ -59,7 +59,7 @@ def _have_exp():
 
 
 def _algos_for(d):
-    algos = ((0, 1, 2, 5, 6, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27) if d == 64
+    algos = ((0, 1, 2, 5, 6, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 29) if d == 64
              else ((0, 1, 2, 13, 14, 16, 21, 23, 24, 26, 28) if d == 128 else (0, 1)))
     return tuple(a for a in algos if a not in _EXPERIMENTAL or _have_exp())
 
@@ -310,7 +310,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     # 13, 14) sum the ROUNDED bf16 weights instead and meet the plain bar; the A/B variants do not.
     def tol(algo):
         return MAX_ABS
-    for algo in (a for a in (0, 5, 6, 13, 14, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 13, 14, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27, 29) if a not in _EXPERIMENTAL or _have_exp()):
         got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo)
         _check(oracle, got, want, fmt, f"optimistic/fallback fmt={fmt} algo={algo}", max_abs=tol(algo))
     # ragged N with the overflow in the partial last tile
@@ -319,7 +319,7 @@ def test_optimistic_pass_overflow_fallback(fa, oracle, torch_cuda, fmt):
     k2[0, n2 - 1] = q2[0, 200] * 40.0
     q2, k2, v2 = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q2, k2, v2))
     want2 = oracle.forward(q2, k2, v2, accum=1, nthreads=8)
-    for algo in (a for a in (0, 5, 6, 13, 14, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27) if a not in _EXPERIMENTAL or _have_exp()):
+    for algo in (a for a in (0, 5, 6, 13, 14, 16, 17, 18, 21, 22, 23, 24, 25, 26, 27, 29) if a not in _EXPERIMENTAL or _have_exp()):
         got2 = _run(fa, torch_cuda, *(oracle.encode16(x, fmt) for x in (q2, k2, v2)), fmt, algo)
         _check(oracle, got2, want2, fmt, f"optimistic/fallback ragged fmt={fmt} algo={algo}", max_abs=tol(algo))
 
@@ -642,7 +642,8 @@ def test_auto_dispatch_boundaries(fa, oracle, torch_cuda, fmt):
     L = fa.lib()
     big = 24
     for (bh, n, want_algo) in [(cus - 1, 512, big), (cus, 512, big), (2 * cus - 1, 256, 6), (2 * cus, 256, 5), (cus, 500, big), (cus // 2, 513, big), (4 * cus, 250, 5),
-                               (cus // 8, 1024, 27), (cus // 4, 1024, 26), (cus // 8, 700, 27), (3 * cus // 2, 512, 26)]:
+                               (cus // 8, 1024, 27), (cus // 4, 1024, 26), (cus // 8, 700, 27), (3 * cus // 2, 512, 26),
+                               (cus // 16, 2048, 29), (cus // 16, 2000, 27)]:   # 128-row workgroups on long sequences: the key split, where N allows it
         sel = L.fa_selected_algo(bh, 1, n, 64, fmt)
         if want_algo is not None:
             assert sel == want_algo, (bh, n, sel)
@@ -729,7 +730,7 @@ def test_folded_pass_gates(fa, oracle, torch_cuda, fmt):
         q, k, v = (oracle.decode16(oracle.encode16(x, fmt), fmt) for x in (q, k, v))
         qb, kb, vb = (oracle.encode16(x, fmt) for x in (q, k, v))
         want = oracle.forward(q, k, v, accum=1, nthreads=8, **({} if scale is None else {"scale": scale}))
-        for algo in (a for a in (24, 26, 27, 23, 22, 21, 0) if a not in _EXPERIMENTAL or _have_exp()):
+        for algo in (a for a in (24, 26, 27, 29, 23, 22, 21, 0) if a not in _EXPERIMENTAL or _have_exp()):
             got = _run(fa, torch_cuda, qb, kb, vb, fmt, algo, scale=scale)
             # (case (i): O = 3 (w1 - w2) with w1 ~ w2 -- the row's output nearly cancels, so a relative measure over the tensor says
             # little; the max-abs bar is what holds there)
@@ -795,10 +796,10 @@ def test_folded_pass_spread_inputs_all_widths(fa, oracle, torch_cuda, fmt):
     (algos 24, 26, 27; d=128: 24, 26) against the oracle on sampled rows and against the exact kernel on all rows."""
     torch = torch_cuda
     dt = _tdtype(torch, fmt)
-    for d, algos in ((64, (24, 26, 27)), (128, (24, 26, 28))):
+    for d, algos in ((64, (24, 26, 27, 29)), (128, (24, 26, 28))):
         for spread in (1.5, 2.0, 3.0):
             g = torch.Generator(device="cuda").manual_seed(int(100 * spread) + d + fmt)
-            q, k, v = (torch.randn(2, 3, 1100, d, generator=g, device="cuda") for _ in range(3))
+            q, k, v = (torch.randn(2, 3, 1152, d, generator=g, device="cuda") for _ in range(3))   # (9 x 128: the key split runs as such)
             q, k, v = (q * spread).to(dt), (k * spread).to(dt), v.to(dt)
             exact = fa.fa_forward(q, k, v, algo=23)
             for algo in algos:
@@ -808,7 +809,7 @@ def test_folded_pass_spread_inputs_all_widths(fa, oracle, torch_cuda, fmt):
                 # two of our kernels against each other: each rounds its weights once (the bar itself does not enter)
                 vmax = float(v.float().abs().max())
                 assert float((o - exact).abs().max()) <= _peaked_tol(fmt, vmax, kernels=2) - MAX_ABS + 1e-3, (d, spread, algo)
-                _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, [(0, 0, 0, 16), (1, 2, 1084, 16), (1, 1, 500, 8)],
+                _sampled_rows_check(fa, oracle, torch, q, k, v, o, fmt, [(0, 0, 0, 16), (1, 2, 1136, 16), (1, 1, 500, 8)],
                                     f"spread {spread} d={d} algo={algo}", max_abs=MAX_ABS if fmt == 0 else _peaked_tol(fmt, vmax),
                                     rel_l2=None if fmt == 0 else 3e-2)
 
