@@ -24,7 +24,10 @@ def one(pattern):
 def is_redo(name):
     """The redo kernel of the full-width pipeline (fa_fwd_rp16_kernel<..., kScan = true, 8>): launched behind every forward of
     those shapes, ends after one look at the marker words unless a row block was left to it.  Reported separately."""
-    return "fa_fwd_rp16_kernel" in name and name.split("(")[0].rstrip().rstrip(">").rstrip().endswith("true, 8")
+    if "fa_fwd_rp16_kernel<" not in name:
+        return False
+    args = [a.strip() for a in name.split("fa_fwd_rp16_kernel<", 1)[1].split(">", 1)[0].split(",")]
+    return len(args) > 7 and args[7] == "true"   # <T, D, X, out, fold, dma, causal, kScan, ...>
 
 
 def pmc_avgs(d, kernel_substr="fa_fwd", redo=False):
