@@ -97,6 +97,9 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #ifndef FA_RP16_PAIR
 #define FA_RP16_PAIR 1             // 1: narrow waves (X <= 2 at D = 64) run TWO tiles per barrier out of a ring of eight slots; 2: every D = 64 width (lab)
 #endif
+#ifndef FA_RP16_OLDS
+#define FA_RP16_OLDS 0             // lab: fp32 outputs at D = 64 go through a wave-private LDS region and leave as whole 256-B rows (four rows per
+#endif                             // store instruction) instead of sixteen 64-B pieces of sixteen rows
 #ifndef FA_RP16_STAGE_SLOT
 #define FA_RP16_STAGE_SLOT 8       // matrix slot (of 32; scaled for narrower steps) of the second step in front of which tile j+2 is written to LDS
 #endif
@@ -1138,6 +1141,26 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     }
     next_in();
     // o[x][db][i] = O[q_row0 + 16x][16 db + 4 g + i]
+    constexpr bool kOLds = FA_RP16_OLDS != 0 && kOutF32 && D == 64 && !kPair && !kScan && kKeySplit == 1 && (FA_RP16_ABL & 32) == 0;
+    if constexpr (kOLds) {
+        // One 16-row block at a time through this wave's 4 KB of LDS behind the ring: written as the accumulators hold it
+        // (lane = row c16, 16-B chunk 4 db + g, chunk index XORed with row & 7: conflict-free both ways), read back with 16
+        // lanes per 256-B row and stored four whole rows per instruction.
+        char* const stg = smem_all + kRingSlots * kSlotBytes + wave * (16u * 256u);
+        const unsigned wr = c16 * 256u, wx = c16 & 7u;
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+#pragma unroll
+            for (int db = 0; db < kDB; ++db)
+                lds_write16(stg, wr + (((4u * db + g) ^ wx) << 4), __builtin_bit_cast(u32x4, o[x][db]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned R = (lane >> 4) + 4u * j, cr = lane & 15u;
+                const u32x4 v = lds_read16(stg, R * 256u + ((cr ^ (R & 7u)) << 4));
+                buf_store16(ro, ((q_row0 - c16 + 16u * x + R) * D + cr * 4u) * 4u, v);
+            }
+        }
+    } else
 #pragma unroll
     for (int x = 0; x < X; ++x) {
         const unsigned row = q_row0 + 16u * x;
@@ -1175,6 +1198,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     constexpr int kW = kWv;
     constexpr int lds_bytes = kKeySplit * ((pair_tiles(D, X, kDma) && kKeySplit == 1) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring(s) of four (eight) [K tile][V tile] slots
     if (kKeySplit > 1 && N % (kBlockN * kKeySplit) != 0) return hipErrorInvalidValue;
+    constexpr int lds_extra = (FA_RP16_OLDS != 0 && kOutF32 && D == 64 && !pair_tiles(D, X, kDma) && kKeySplit == 1) ? kWv * 16 * 256 : 0;   // the output staging region
     constexpr int kRows = 16 * X * kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
@@ -1182,9 +1206,9 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     const long long cap = device_cus();
     const unsigned grid = nwg > cap ? (unsigned)cap : (unsigned)nwg;
     auto kern = fa_fwd_rp16_kernel<T, D, X, kOutF32, kFold, kDma, kCausal, false, kWv, kKeySplit>;
-    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes);
+    const hipError_t attr = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes + lds_extra);
     if (attr != hipSuccess) return attr;
-    FA_LAUNCH(kern, dim3(grid), dim3(64 * kW * kKeySplit), lds_bytes, stream,
+    FA_LAUNCH(kern, dim3(grid), dim3(64 * kW * kKeySplit), lds_bytes + lds_extra, stream,
               static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), static_cast<const uint16_t*>(V), O, N, nqb,
               scale * kLog2e, (unsigned)nwg);
     if (launch_status() != hipSuccess) return launch_status();
