@@ -789,6 +789,32 @@ def test_folded_pass_matches_exact_on_bench_data(fa, oracle, torch_cuda, fmt):
     _sampled_rows_check(fa, oracle, torch, q, k, v, a, fmt, [(0, 0, 0, 32), (1, 15, 4064, 32), (1, 7, 2000, 16)], "folded pass")
 
 
+def test_redo_kernel_takes_the_blocks_the_fast_passes_refuse(fa, oracle, torch_cuda):
+    """fp16 inputs spread x2 (logits of +-40 log2 units) at the full width: every 512-row block is refused by the folded pass
+    before its first tile and left to the redo kernel (pass id 3: the running-max pass on half-width waves, launched behind
+    the forward); the result is checked against the oracle on sampled rows and against the exact kernel on all rows.
+    bf16 at the same spread stays in the forward (its exact optimistic pass cannot overflow there)."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q, k, v = (torch.randn(2, 8, 4096, 64, generator=g, device="cuda") for _ in range(3))
+    for fmt, want_redo in ((0, True), (1, False)):
+        dt = _tdtype(torch, fmt)
+        qq, kk, vv = (q * 2.0).to(dt), (k * 2.0).to(dt), v.to(dt)
+        ids, o_exp = _pass_ids(torch, qq, kk, vv, 24)
+        if want_redo:
+            assert (ids == 3).all(), np.bincount(ids, minlength=4)
+        else:
+            assert (ids <= 1).all(), np.bincount(ids, minlength=4)
+        o = fa.fa_forward(qq, kk, vv, algo=24)
+        torch.cuda.synchronize()
+        assert torch.equal(o, o_exp)
+        vmax = float(vv.float().abs().max())
+        exact = fa.fa_forward(qq, kk, vv, algo=23)
+        assert float((o - exact).abs().max()) <= _peaked_tol(fmt, vmax, kernels=2) - MAX_ABS + 1e-3
+        _sampled_rows_check(fa, oracle, torch, qq, kk, vv, o, fmt, [(0, 0, 0, 16), (1, 7, 4080, 16), (1, 3, 2047, 8)],
+                            f"redo kernel fmt={fmt}", max_abs=MAX_ABS if fmt == 0 else _peaked_tol(fmt, vmax), rel_l2=None if fmt == 0 else 3e-2)
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_folded_pass_spread_inputs_all_widths(fa, oracle, torch_cuda, fmt):
     """Q and K spread x1.5 / x2 / x3 (logits x2.25 / x4 / x9): where the wave reference is placed, the gates and the
