@@ -34,16 +34,38 @@ __device__ __forceinline__ void sfor(F&& f) {
     sfor_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 template <typename T> struct Mx;
+// mfma_v*: the same instruction spelled out with its accumulator in ARCHITECTURAL registers.  A kernel that may use the
+// accumulator half of the file (one wave per SIMD) gets every builtin matrix instruction in the form whose C/D live there:
+// right for O and the row sums (only matrix instructions touch them), wrong for the scores (one v_accvgpr_read per score).
+// The compiler does not know these statements are matrix instructions: the wait states between one of them and the first
+// vector instruction that reads its result are the CALLER's (see kAsmQK; tools/mfma_hazard_lint.py checks the listing).
+#define FA_MFMA_V(NAME, SFX)                                                                                              \
+    static __device__ __forceinline__ void mfma_v_acc(f32x4& acc, u32x4 a, u32x4 b) {                                     \
+        asm("v_mfma_f32_16x16x32_" SFX " %0, %1, %2, %0 ; fa_qk" : "+v"(acc) : "v"(a), "v"(b));                           \
+    }                                                                                                                     \
+    static __device__ __forceinline__ f32x4 mfma_v_init(u32x4 a, u32x4 b, f32x4 c) {                                      \
+        f32x4 d;                                                                                                          \
+        asm("v_mfma_f32_16x16x32_" SFX " %0, %1, %2, %3 ; fa_qk" : "=&v"(d) : "v"(a), "v"(b), "v"(c));                    \
+        return d;                                                                                                         \
+    }                                                                                                                     \
+    static __device__ __forceinline__ f32x4 mfma_v_zero(u32x4 a, u32x4 b) {                                               \
+        f32x4 d;                                                                                                          \
+        asm("v_mfma_f32_16x16x32_" SFX " %0, %1, %2, 0 ; fa_qk" : "=&v"(d) : "v"(a), "v"(b));                             \
+        return d;                                                                                                         \
+    }
 template <> struct Mx<F16> {
     static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
+    FA_MFMA_V(F16, "f16")
 };
 template <> struct Mx<BF16> {
     static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    FA_MFMA_V(BF16, "bf16")
 };
+#undef FA_MFMA_V
 constexpr int kW = 8;
 #ifndef FA_RP16_AHEAD
 #define FA_RP16_AHEAD 2
@@ -96,6 +118,9 @@ constexpr float kFoldShiftMin = 6.0f;  // ... and how far below the first scores
 #endif
 #ifndef FA_RP16_PAIR
 #define FA_RP16_PAIR 1             // 1: narrow waves (X <= 2 at D = 64) run TWO tiles per barrier out of a ring of eight slots; 2: every D = 64 width (lab)
+#endif
+#ifndef FA_RP16_ASMQK
+#define FA_RP16_ASMQK 1
 #endif
 #ifndef FA_RP16_OLDS
 #define FA_RP16_OLDS 0             // lab: fp32 outputs at D = 64 go through a wave-private LDS region and leave as whole 256-B rows (four rows per
@@ -205,6 +230,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr unsigned kTile = kBlockN * D * 2;
     constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
     constexpr bool kPair = pair_tiles(D, X, kDma) && kKeySplit == 1;   // (two rings of eight slots do not fit)
+    // one wave per SIMD: QK^T spelled out with the scores in architectural registers (Mx::mfma_v*).  Every vector read of a score
+    // lies at least X P.V matrix instructions behind the instruction that wrote it (the units alternate QK^T and P.V fragments and a
+    // step ends with a P.V fragment); the prologue, whose reference maximum reads unit 0 at once, waits explicitly (settle).
+    constexpr bool kAsmQK = FA_RP16_ASMQK != 0 && kWv == 4;
     constexpr unsigned kRingSlots = kPair ? 8u : 4u, kRingMask = kRingSlots - 1u;
     constexpr int kLook = kPair ? 3 : 2;            // a tile is landed this many tiles ahead of the iteration that starts with it
     extern __shared__ __attribute__((aligned(16))) char smem_all[];   // one ring of slots per key-split group
@@ -667,10 +696,13 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             if constexpr ((f & 1) == 0) {
                 constexpr int kbl = (f >> 1) / kKS, ks = (f >> 1) % kKS;
                 using MQ = std::conditional_t<kCvtK && kFast, Mx<F16>, M>;
-                // (kWv == 4, one wave per SIMD: the allocator keeps these accumulators in the accumulator half of the file and copies
-                // every score out with a v_accvgpr_read -- 64 per tile.  Spelling the instruction out with the scores in architectural
-                // registers and Q in the accumulator half was tried: it then copies Q IN per use instead and spills; left as is.)
-                s_nxt[x][kbl] = MQ::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
+                if constexpr (kAsmQK) {
+                    if constexpr (ks != 0) MQ::mfma_v_acc(s_nxt[x][kbl], frag[f % kRing], qf[x][ks]);
+                    else if constexpr (kFast) s_nxt[x][kbl] = MQ::mfma_v_init(frag[f % kRing], qf[x][ks], minit);
+                    else s_nxt[x][kbl] = MQ::mfma_v_zero(frag[f % kRing], qf[x][ks]);
+                } else {
+                    s_nxt[x][kbl] = MQ::mfma(frag[f % kRing], qf[x][ks], ks == 0 ? (kFast ? minit : zero4) : s_nxt[x][kbl]);
+                }
             } else {
                 constexpr int db = f >> 1;
                 o[x][db] = M::mfma(frag[f % kRing], pk_prev[x], o[x][db]);
@@ -778,8 +810,16 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 const u32x4 kf = read_kf(0u, 0, kbl, ks);
                 using MQ = std::conditional_t<kCvtK && kFast, Mx<F16>, M>;
 #pragma unroll
-                for (int x = 0; x < X; ++x) sA[x][kbl] = MQ::mfma(kf, qf[x][ks], ks == 0 ? zero4 : sA[x][kbl]);
+                for (int x = 0; x < X; ++x) {
+                    if constexpr (!kAsmQK) sA[x][kbl] = MQ::mfma(kf, qf[x][ks], ks == 0 ? zero4 : sA[x][kbl]);
+                    else if (ks == 0) sA[x][kbl] = MQ::mfma_v_zero(kf, qf[x][ks]);
+                    else MQ::mfma_v_acc(sA[x][kbl], kf, qf[x][ks]);
+                }
             }
+        if constexpr (kAsmQK) {   // the matrix results are read by vector instructions right below: 16 wait states behind each
+#pragma unroll
+            for (int x = 0; x < X; ++x) asm volatile("s_nop 15" : "+v"(sA[x][0]), "+v"(sA[x][1]));
+        }
         {
             // reference max from the first 32 keys (masked copy when N < 32; the step masks again)
             f32x4 s0[X][2];

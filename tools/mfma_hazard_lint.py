@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Wait-state lint for the matrix instructions that fa_fwd_rp16_kernel.hpp spells out as inline asm (Mx::mfma_v*, marked
+"; fa_qk" in the listing).  The compiler's hazard recogniser does not look inside an asm statement, so nothing inserts the
+wait states gfx950 requires between an XDL instruction that writes architectural registers and the first NON-matrix
+instruction that reads or overwrites them (8-pass 16x16x32: 11; we ask for 12).  This walks the listing from every marked
+instruction along fall-through and branch edges and fails if such an instruction is reachable in fewer wait states.
+Counting is conservative: a matrix instruction = 4 (its minimum issue time), s_nop N = N + 1, anything else = 1.
+
+    python tools/mfma_hazard_lint.py flashattention_kernel_project_amd/csrc/fa_fwd_rp16_d128w.hip [-DFLAG ...]
+"""
+import re
+import subprocess
+import sys
+import tempfile
+
+NEED = 12
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-fvisibility=hidden", "-S", "--cuda-device-only"]
+
+
+def regs(tok):
+    """architectural registers named by an operand token: v7 -> {7}, v[4:7] -> {4..7}"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def operands(line):
+    body = line.split(";")[0].strip()
+    parts = body.split(None, 1)
+    if len(parts) < 2:
+        return parts[0] if parts else "", []
+    return parts[0], [t.strip() for t in parts[1].split(",")]
+
+
+def lint_function(name, lines):
+    labels = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+    worst, bad = 10 ** 9, []
+    marked = [i for i, l in enumerate(lines) if "fa_qk" in l and "v_mfma" in l]
+    for i in marked:
+        _, ops = operands(lines[i])
+        dst = regs(ops[0])
+        # (position, wait states so far); stop a path at NEED
+        stack, seen = [(i + 1, 0)], set()
+        while stack:
+            pos, ws = stack.pop()
+            while pos < len(lines) and ws < NEED:
+                if (pos, ws) in seen:
+                    break
+                seen.add((pos, ws))
+                l = lines[pos]
+                op, ops2 = operands(l)
+                if not op or op.endswith(":") or op.startswith(".") or op.startswith(";"):
+                    pos += 1
+                    continue
+                used = set()
+                for t in ops2:
+                    for w in t.split():
+                        used |= regs(w)
+                if op.startswith("v_mfma"):
+                    # same-destination accumulation (srcC == vDst, same opcode) needs no wait; A/B reads of the scores do not occur
+                    if used & dst and regs(ops2[0]) != dst:
+                        bad.append((i, pos, ws, l.strip()))
+                    ws += 4
+                elif used & dst:
+                    worst = min(worst, ws)
+                    bad.append((i, pos, ws, l.strip()))
+                    break
+                elif op == "s_nop":
+                    ws += int(ops2[0]) + 1
+                else:
+                    ws += 1
+                if op in ("s_branch",):
+                    pos = labels.get(ops2[0], len(lines))
+                    continue
+                if op.startswith("s_cbranch"):
+                    tgt = labels.get(ops2[0])
+                    if tgt is not None:
+                        stack.append((tgt, ws))
+                if op in ("s_endpgm", "s_setpc_b64"):
+                    break
+                pos += 1
+    return len(marked), bad
+
+
+def main():
+    src, extra = sys.argv[1], sys.argv[2:]
+    with tempfile.NamedTemporaryFile(suffix=".s") as f:
+        inc = ["-I" + src.rsplit("/", 1)[0]] if "/" in src else []
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + inc + extra + [src, "-o", f.name], capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr[-2000:])
+            return 2
+        txt = open(f.name).read().split("\n")
+    fn, cur, total_marked, total_bad = None, [], 0, 0
+    for l in txt:
+        m = re.match(r"^(_Z\S+):", l)
+        if m and fn is None:
+            fn, cur = m.group(1), []
+            continue
+        if fn is not None:
+            if l.startswith(".Lfunc_end"):
+                n, bad = lint_function(fn, cur)
+                total_marked += n
+                total_bad += len(bad)
+                if n:
+                    print(f"{fn[:110]}: {n} spelled-out matrix instructions, {len(bad)} too close")
+                for i, pos, ws, text in bad[:10]:
+                    print(f"    {cur[i].strip()[:70]}  ->  after {ws} wait states: {text[:90]}")
+                fn = None
+            else:
+                cur.append(l)
+    print(f"total: {total_marked} spelled-out matrix instructions, {total_bad} hazards (need {NEED} wait states)")
+    return 1 if total_bad or not total_marked else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
