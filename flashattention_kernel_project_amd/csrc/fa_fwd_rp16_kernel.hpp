@@ -860,7 +860,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 for (int x = 0; x < X; ++x) m_ref[x] = mw;
                 // the gates that are known now (reference beyond kFoldMax, folded Q out of range) end the pass before it costs
                 // anything: one workgroup vote per item
-                if (__syncthreads_or((!(fabsf(mw) <= kFoldMax) || q_bad != 0) ? 1 : 0)) return true;
+                if (__syncthreads_or(((((FA_RP16_GATES & 4) != 0) && !(fabsf(mw) <= kFoldMax)) || (((FA_RP16_GATES & 8) != 0) && q_bad != 0)) ? 1 : 0)) return true;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) minit[i] = -mw;
 #pragma unroll

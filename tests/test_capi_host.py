@@ -115,3 +115,19 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "fa_mi355.h"\nint main(void) { return (int)sizeof(size_t) == 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                            "-o", str(tmp_path / "hdr.o")])
+
+
+def test_spelled_out_matrix_instructions_keep_their_wait_states():
+    """The one-wave-per-SIMD kernel (id 28) spells QK^T out as inline asm, which the compiler's hazard recogniser does not
+    look into: tools/mfma_hazard_lint.py walks the gfx950 listing and fails on any vector instruction closer than the
+    required wait states behind (or, for producers of the operands, in front of) one of those instructions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_lint.py"),
+                        os.path.join(root, "flashattention_kernel_project_amd", "csrc", "fa_fwd_rp16_d128w.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert re.search(r"total: \d+ spelled-out matrix instructions, 0 hazards", r.stdout), r.stdout[-500:]

@@ -12,8 +12,14 @@ SRCS="fa_fwd_kernels.hip fa_fwd_il.hip fa_fwd_rp16.hip fa_fwd_rp16_d64.hip fa_fw
 pids=()
 for s in $SRCS; do
   # only fa_fwd_sk.hip and fa_capi.hip depend on the knobs in practice; the rest are reused from the product build
-  # only the d = 64 full-width family depends on the FA_RP16_* knobs in practice (ALL=1 rebuilds every rp16 family); the rest are reused from the product build
-  if [ "$s" = "fa_fwd_rp16_d64.hip" ] || { [ -n "$ALL" ] && [[ "$s" == fa_fwd_rp16_* ]]; } || [ ! -f "$src/${s%.hip}.o" ]; then
+  # ONLY=<file.hip> rebuilds exactly that translation unit; otherwise only the d = 64 full-width family depends on the FA_RP16_* knobs in practice (ALL=1 rebuilds every rp16 family); the rest are reused from the product build
+  if [ -n "$ONLY" ]; then want=$([ "$s" = "$ONLY" ] && echo 1 || echo 0); else want=-1; fi
+  if [ "$want" = 1 ] || [ ! -f "$src/${s%.hip}.o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS $extra -c "$src/$s" -o "$obj/${s%.hip}.o" &
+    pids+=($!)
+  elif [ "$want" = 0 ]; then
+    cp "$src/${s%.hip}.o" "$obj/${s%.hip}.o"
+  elif [ "$s" = "fa_fwd_rp16_d64.hip" ] || { [ -n "$ALL" ] && [[ "$s" == fa_fwd_rp16_* ]]; } || [ ! -f "$src/${s%.hip}.o" ]; then
     /opt/rocm/bin/hipcc $FLAGS $extra -c "$src/$s" -o "$obj/${s%.hip}.o" &
     pids+=($!)
   else

@@ -4,6 +4,12 @@
 wait states gfx950 requires between an XDL instruction that writes architectural registers and the first NON-matrix
 instruction that reads or overwrites them (8-pass 16x16x32: 11; we ask for 12).  This walks the listing from every marked
 instruction along fall-through and branch edges and fails if such an instruction is reachable in fewer wait states.
+The other direction is checked inside the basic block (and across the loop back-edge of a self-looping block): a vector
+instruction (v_accvgpr_write/read copies the register allocator puts in, conversions, moves) that writes a source
+register of a marked instruction fewer than NEED_IN wait states in front of it, or a matrix instruction that writes one
+(other than the marked instruction's own accumulator chain) fewer than NEED wait states in front -- this is how a
+128-row-wave d = 64 variant failed (the allocator re-copied Q fragments into accumulator registers right in front of
+their use).
 Counting is conservative: a matrix instruction = 4 (its minimum issue time), s_nop N = N + 1, anything else = 1.
 
     python tools/mfma_hazard_lint.py flashattention_kernel_project_amd/csrc/fa_fwd_rp16_d128w.hip [-DFLAG ...]
@@ -14,18 +20,66 @@ import sys
 import tempfile
 
 NEED = 12
+NEED_IN = 4
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-fvisibility=hidden", "-S", "--cuda-device-only"]
 
 
-def regs(tok):
-    """architectural registers named by an operand token: v7 -> {7}, v[4:7] -> {4..7}"""
-    m = re.fullmatch(r"v(\d+)", tok)
+def regs(tok, cls="v"):
+    """registers of class cls named by an operand token: v7 -> {7}, v[4:7] -> {4..7}"""
+    m = re.fullmatch(cls + r"(\d+)", tok)
     if m:
         return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    m = re.fullmatch(cls + r"\[(\d+):(\d+)\]", tok)
     if m:
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
     return set()
+
+
+def both(tok):
+    return {("v", r) for r in regs(tok, "v")} | {("a", r) for r in regs(tok, "a")}
+
+
+def inbound(lines, i, labels):
+    """hazards in FRONT of the marked instruction lines[i]: (position, wait states, text) of too-close producers"""
+    _, ops = operands(lines[i])
+    dst = both(ops[0])
+    srcs = set()
+    for t in ops[1:4]:
+        srcs |= both(t)
+    chain = dst & both(ops[3]) if len(ops) > 3 else set()   # the accumulator chain (srcC == vDst) is interlocked
+    out, ws, pos, wrapped = [], 0, i - 1, False
+    while ws < NEED:
+        if pos < 0:
+            break
+        l = lines[pos]
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:   # top of the block: follow the back-edge of a self-looping block once, else stop (other predecessors are
+            if wrapped:   # reached through at least a branch and the block's own instructions)
+                break
+            tail = [k for k in range(i, len(lines)) if re.match(r"\s+s_cbranch\S+\s+" + re.escape(m.group(1)) + r"\s*$", lines[k].split(";")[0])]
+            if not tail:
+                break
+            pos, wrapped = tail[0] - 1, True
+            continue
+        op, ops2 = operands(l)
+        if not op or op.endswith(":") or op.startswith(".") or op.startswith(";"):
+            pos -= 1
+            continue
+        writes = both(ops2[0]) if ops2 and (op.startswith("v_") or op.startswith("ds_read") or op.startswith("buffer_load") or op.startswith("scratch_load")) else set()
+        if op.startswith("v_mfma"):
+            if (writes & srcs) - chain:
+                out.append((pos, ws, l.strip()))
+            ws += 4
+        elif op.startswith("v_") and writes & srcs:
+            if ws < NEED_IN:
+                out.append((pos, ws, l.strip()))
+            ws += 1
+        elif op == "s_nop":
+            ws += int(ops2[0]) + 1
+        else:
+            ws += 1
+        pos -= 1
+    return out
 
 
 def operands(line):
@@ -87,6 +141,9 @@ def lint_function(name, lines):
                 if op in ("s_endpgm", "s_setpc_b64"):
                     break
                 pos += 1
+    for i in marked:
+        for pos, ws, text in inbound(lines, i, labels):
+            bad.append((i, pos, ws, "(in front) " + text))
     return len(marked), bad
 
 
