@@ -138,6 +138,24 @@ __device__ __forceinline__ u32x4 lds_read16(const char* smem, unsigned off) {
 __device__ __forceinline__ void lds_write16(char* smem, unsigned off, u32x4 v) {
     *reinterpret_cast<u32x4*>(smem + off) = v;
 }
+// the same by LDS byte ADDRESS (lds_addr(smem) + offset): callers that keep whole addresses in registers and want the rest of
+// it in the instruction's immediate
+__device__ __forceinline__ unsigned lds_addr(const char* smem) {
+    return (unsigned)(size_t)(const lds_char*)smem;
+}
+__device__ __forceinline__ u32x4 lds_read16_at(unsigned addr) {
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    return *(const lds_u32x4*)(size_t)addr;
+}
+__device__ __forceinline__ void lds_write16_at(unsigned addr, u32x4 v) {
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    *(lds_u32x4*)(size_t)addr = v;
+}
+__device__ __forceinline__ u32x2 lds_read_tr8_at(unsigned addr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)addr);
+    return __builtin_bit_cast(u32x2, v);
+}
 // ds_read_b64_tr_b16: per 16-lane group a [4 rows][16 cols] block of 16-bit elements comes back
 // column-major; lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i.
 __device__ __forceinline__ u32x2 lds_read_tr8(const char* smem, unsigned off) {

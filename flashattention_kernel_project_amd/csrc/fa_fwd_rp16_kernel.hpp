@@ -220,9 +220,17 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // LDS instructions a wave issues in the second step behind the landing of tile j+2 (fragment reads: one ds_read_b128 per K
     // fragment, two ds_read_b64_tr_b16 per V^T fragment)
     constexpr int kLandSlot = FA_RP16_STAGE_SLOT * kSlots / 32;
+    // one wave per SIMD: no second wave issues while this one works through a bunch of loads or LDS writes, so tile j+2 is
+    // requested one chunk per matrix slot (first step) and landed one chunk per slot (second step, from kLandSlot on)
+#ifndef FA_RP16_SPREAD
+#define FA_RP16_SPREAD 1
+#endif
+    constexpr bool kSpread = FA_RP16_SPREAD != 0 && kWv == 4 && !kDma && !pair_tiles(D, X, kDma);
+    constexpr int kLandLast = kSpread ? kLandSlot + 2 * kLoads - 1 : kLandSlot;   // the slot of the last landing write
+    static_assert(kLandLast < kSlots && 2 * kLoads <= kSlots, "the landing fits the step");
     constexpr int kLdsAfterLand = [] {
         int n = 0;
-        for (int i = kLandSlot; i < kSlots; ++i)
+        for (int i = kLandLast; i < kSlots; ++i)
             if (i % X == X - 1) n += ((i / X + kAhead) & 1) ? 2 : 1;
         return n;
     }();
@@ -477,6 +485,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     locate(bid, bh, qb);
     const __amdgpu_buffer_rsrc_t rk = make_rsrc(Kg + bh * head_elems + kv_first, kv_bytes);
     const __amdgpu_buffer_rsrc_t rv = make_rsrc(Vg + bh * head_elems + kv_first, kv_bytes);
+    [[maybe_unused]] const char* const k_head = reinterpret_cast<const char*>(Kg + bh * head_elems + kv_first);
+    [[maybe_unused]] const char* const v_head = reinterpret_cast<const char*>(Vg + bh * head_elems + kv_first);
     const unsigned q_row0 = qb * kRows + wave * (16u * X) + c16;   // row of block 0; block x is 16x rows further
     // causal: tiles [0, nt) with nt up to the diagonal of the workgroup's last (existing) row; tiles >= jc cross its row range
     const int nt = kCausal ? min(ntiles, (int)(min((unsigned)N - 1u, qb * kRows + kRows - 1u) / kBlockN) + 1) : ntiles;
@@ -553,6 +563,27 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
         return vf;
     };
+    // kBases (one wave per SIMD): a step's fragment addresses from per-step lane bases (ring slot + lane offset, one v_add
+    // each at the top of the step) plus immediates, instead of one s_add + v_add in front of every fragment read -- with a
+    // lone wave per SIMD every such instruction is a cycle the matrix pipe waits for
+    constexpr bool kBases = kSpread && FA_RP16_VFIX == 2 && (FA_RP16_ABL & 257) == 0;
+    auto read_frag_b = [&](auto fc, const unsigned (&kb)[kKS], unsigned vb, int h_q, int h_v) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr ((f & 1) == 0) {
+            constexpr int kbl = (f >> 1) / kKS, ks = (f >> 1) % kKS;
+            frag[f % kRing] = lds_read16_at(kb[ks] + (unsigned)(2 * h_q + kbl) * 16u * kRowB);
+        } else {
+            constexpr int db = f >> 1;
+            u32x4 vf;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const u32x2 half = lds_read_tr8_at(vb + (4u * h_v + 2u * jj) * (unsigned)kDB * 256u + db * 256u);
+                vf[2 * jj] = half[0];
+                vf[2 * jj + 1] = half[1];
+            }
+            frag[f % kRing] = vf;
+        }
+    };
     // fragment f (0..kNF-1) of a step: even f -> K fragment (kbl = (f/2) / kKS, ks = (f/2) % kKS) of the QK^T unit,
     // odd f -> V^T fragment db = f/2 of the PV unit
     auto read_frag = [&](auto fc, unsigned so_q, int h_q, unsigned so_v, int h_v) {
@@ -590,7 +621,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // (so_q, 1-h) -> s_nxt, the PV unit (so_v, 1-h) <- pk_prev.  so_nq / so_nv: slots of the NEXT step's units.
     auto step = [&](auto h_c, auto masked_c, auto fast_c, auto track_c, int tile, f32x4 (&s_cur)[X][2], f32x4 (&s_nxt)[X][2],
                     u32x4 (&pk_prev)[X], u32x4 (&pk_cur)[X], unsigned so_q, unsigned so_v, unsigned so_nq, unsigned so_nv,
-                    unsigned so_land, auto set_c) __attribute__((always_inline)) {
+                    unsigned so_land, auto set_c, auto req_c) __attribute__((always_inline)) {
         u32x4 (&k_land)[kLoads] = decltype(set_c)::value == 0 ? kst : kst2;   // the staging registers this step lands (h = 1)
         u32x4 (&v_land)[kLoads] = decltype(set_c)::value == 0 ? vst : vst2;
         constexpr int h = decltype(h_c)::value, ho = 1 - h;
@@ -714,10 +745,76 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             fma_pair(c1{});
         }
         if constexpr ((FA_RP16_ABL & 2) == 0) exp_pair(c0{});
+        [[maybe_unused]] unsigned kb_q[kKS], kb_n[kKS], vb_v = 0u, vb_n = 0u, land_k = 0u, land_v = 0u;
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t rk_t = rk, rv_t = rv;
+        // (each base is formed behind the matrix instruction in front of its first read, not in a bunch at the top of the step)
+        static_assert(!kBases || kAhead == 2, "the fragments read ahead into the next step are K(0, 0) and V(0)");
+        auto form_base = [&](auto fc) {
+            constexpr int f = decltype(fc)::value;   // fragment about to be read; f >= kNF: of the next step
+            const unsigned smem_a = lds_addr(smem);
+            if constexpr (f >= kNF) {
+                if constexpr (f == kNF) { kb_n[0] = smem_a + so_nq + k_rd[0]; asm volatile("" : "+v"(kb_n[0])); }
+                if constexpr (f == kNF + 1) { vb_n = smem_a + so_nv + v_rd4[0]; asm volatile("" : "+v"(vb_n)); }
+            } else if constexpr ((f & 1) == 0) {
+                constexpr int ks = (f >> 1) % kKS;
+                if constexpr (f - 2 * kKS < kAhead) {   // no earlier in-step fragment with this ks
+                    kb_q[ks] = smem_a + so_q + k_rd[ks];
+                    asm volatile("" : "+v"(kb_q[ks]));
+                }
+            } else if constexpr (f - 2 < kAhead) {
+                vb_v = smem_a + so_v + v_rd4[0];
+                asm volatile("" : "+v"(vb_v));
+            }
+        };
         sfor<kSlots>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (h == 1 && i == kLandSlot && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
+            if constexpr (kSpread && (FA_RP16_ABL & 8) == 0) {
+                if constexpr (h == 0 && i < 2 * kLoads && decltype(req_c)::value) {   // request chunk i of tile j+2
+                    constexpr int p = i >> 1;
+                    if constexpr (kBases) {
+                        // the tile's offset goes into the DESCRIPTOR (base up, bytes down: scalar instructions, and the bounds still
+                        // cut at the end of the head) instead of into eight per-lane offsets
+                        if constexpr (i == 0) {
+                            const unsigned t_off = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(tile + kLook) * kTile);
+                            const unsigned left = (unsigned)__builtin_amdgcn_readfirstlane(t_off < kv_bytes ? kv_bytes - t_off : 0u);
+                            auto uniform_ptr = [](const char* q) -> const char* {   // (uniform anyway: spares the descriptor a waterfall loop)
+                                const unsigned long long a = (unsigned long long)q;
+                                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+                                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+                                return reinterpret_cast<const char*>((unsigned long long)lo | ((unsigned long long)hi << 32));
+                            };
+                            rk_t = make_rsrc(uniform_ptr(k_head + t_off), left);
+                            rv_t = make_rsrc(uniform_ptr(v_head + t_off), left);
+                        }
+                        if constexpr ((i & 1) == 0) kst[p] = buf_load16(rk_t, st_goff[p]);
+                        else vst[p] = buf_load16(rv_t, sv_goff[p]);
+                    } else {
+                        if constexpr ((i & 1) == 0) kst[p] = buf_load16(rk, (unsigned)(tile + kLook) * kTile + st_goff[p]);
+                        else vst[p] = buf_load16(rv, (unsigned)(tile + kLook) * kTile + sv_goff[p]);
+                    }
+                }
+                if constexpr (h == 1 && i >= kLandSlot && i <= kLandLast) {   // land chunk i - kLandSlot
+                    constexpr int p = (i - kLandSlot) >> 1;
+                    if constexpr (kBases) {
+                        // chunk p of a thread lies 64 kW / kChunks rows below chunk 0 in both images (the K swizzle and the V block
+                        // map repeat every 16 rows at D = 128): one address each, the rest in the immediate
+                        static_assert(!kBases || (D == 128 && (64 * kW) % G::kChunks == 0 && ((64 * kW) / G::kChunks) % 16 == 0), "chunk p = chunk 0 + p rows");
+                        constexpr unsigned kStepK = (64u * kW / G::kChunks) * kRowB, kStepV = (64u * kW / G::kChunks / 8u) * (unsigned)kDB * 256u;
+                        if constexpr (i == kLandSlot) {
+                            land_k = lds_addr(smem) + so_land + k_lds[0];
+                            asm volatile("" : "+v"(land_k));
+                            land_v = lds_addr(smem) + so_land + v_lds[0];
+                            asm volatile("" : "+v"(land_v));
+                        }
+                        if constexpr (((i - kLandSlot) & 1) == 0) lds_write16_at(land_k + p * kStepK, (kCvtK && kFast) ? k_to_f16(k_land[p]) : k_land[p]);
+                        else lds_write16_at(land_v + p * kStepV, v_land[p]);
+                    } else {
+                        if constexpr (((i - kLandSlot) & 1) == 0) lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(k_land[p]) : k_land[p]);
+                        else lds_write16(smem, so_land + v_lds[p], v_land[p]);
+                    }
+                }
+            } else if constexpr (h == 1 && i == kLandSlot && !kDma && (FA_RP16_ABL & 8) == 0) {   // land tile j+2 (requested at the top of the iteration)
 #pragma unroll
                 for (int p = 0; p < kLoads; ++p) {
                     lds_write16(smem, so_land + k_lds[p], (kCvtK && kFast) ? k_to_f16(k_land[p]) : k_land[p]);
@@ -732,8 +829,14 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             }
             if constexpr (i % X == X - 1) {   // the fragment just consumed X times is free: read kAhead ahead
                 constexpr int f = i / X + kAhead;
-                if constexpr (f < kNF) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
-                else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
+                if constexpr (kBases) {
+                    form_base(std::integral_constant<int, f>{});
+                    if constexpr (f < kNF) read_frag_b(std::integral_constant<int, f>{}, kb_q, vb_v, ho, ho);
+                    else read_frag_b(std::integral_constant<int, f - kNF>{}, kb_n, vb_n, h, h);
+                } else {
+                    if constexpr (f < kNF) read_frag(std::integral_constant<int, f>{}, so_q, ho, so_v, ho);
+                    else read_frag(std::integral_constant<int, f - kNF>{}, so_nq, h, so_nv, h);
+                }
             }
             constexpr int kPer = kSlots / kPairs;   // matrix slots per vector pair-step (2 at D = 64, 4 at D = 128)
             if constexpr (kVSplit && (FA_RP16_ABL & 2) == 0) {
@@ -901,7 +1004,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             const unsigned so_m1 = ((jj + kRingMask) & kRingMask) * kSlotBytes, so_0 = (jj & kRingMask) * kSlotBytes;
             const unsigned so_p1 = ((jj + 1u) & kRingMask) * kSlotBytes, so_ld = ((jj + (unsigned)kLook) & kRingMask) * kSlotBytes;
             // tile j + kLook: tiles past the end read zeros through the buffer bounds into a free slot
-            if constexpr ((FA_RP16_ABL & 8) != 0 || !decltype(req_c)::value) {
+            if constexpr ((FA_RP16_ABL & 8) != 0 || !decltype(req_c)::value || kSpread) {   // (kSpread: inside the first step)
             } else if constexpr (kDma) {
                 dma_tile(rk, rv, (unsigned)(j + 2) * kTile, so_ld);   // the barrier below waits for it (vmcnt) and publishes it
             } else {
@@ -913,8 +1016,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
             }
             //   h 0: softmax (j,0);  QK^T (j,1);    PV (j-1,1);  next step: QK^T (j+1,0), PV (j,0)
             //   h 1: softmax (j,1);  QK^T (j+1,0);  PV (j,0);    next step: QK^T (j+1,1), PV (j,1)
-            step(c0{}, masked_c, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_ld, c0{});
-            step(c1{}, masked_c, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_ld, c0{});
+            step(c0{}, masked_c, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_ld, c0{}, req_c);
+            step(c1{}, masked_c, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_ld, c0{}, req_c);
             tile_barrier();
         };
         // kPair: tiles j and j+1 in one iteration: tiles j+3 and j+4 requested at the top and landed in the second step of each tile,
@@ -933,10 +1036,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     vst2[p] = buf_load16(rv, (unsigned)(j + 4) * kTile + sv_goff[p]);
                 }
             }
-            step(c0{}, no, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p3, c0{});
-            step(c1{}, no, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p3, c0{});
-            step(c0{}, no, fast_c, track_c, j + 1, sA, sB, pkB, pkA, so_p1, so_0, so_p2, so_p1, so_p4, c1{});
-            step(c1{}, no, fast_c, track_c, j + 1, sB, sA, pkA, pkB, so_p2, so_p1, so_p2, so_p1, so_p4, c1{});
+            step(c0{}, no, fast_c, track_c, j, sA, sB, pkB, pkA, so_0, so_m1, so_p1, so_0, so_p3, c0{}, no);
+            step(c1{}, no, fast_c, track_c, j, sB, sA, pkA, pkB, so_p1, so_0, so_p1, so_0, so_p3, c0{}, no);
+            step(c0{}, no, fast_c, track_c, j + 1, sA, sB, pkB, pkA, so_p1, so_0, so_p2, so_p1, so_p4, c1{}, no);
+            step(c1{}, no, fast_c, track_c, j + 1, sB, sA, pkA, pkB, so_p2, so_p1, so_p2, so_p1, so_p4, c1{}, no);
             tile_barrier();
         };
         if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(3);
