@@ -151,6 +151,14 @@ __device__ __forceinline__ void lds_write16_at(unsigned addr, u32x4 v) {
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     *(lds_u32x4*)(size_t)addr = v;
 }
+__device__ __forceinline__ unsigned lds_read4_at(unsigned addr) {
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    return *(const volatile lds_u32*)(size_t)addr;
+}
+__device__ __forceinline__ void lds_write4_at(unsigned addr, unsigned v) {
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    *(volatile lds_u32*)(size_t)addr = v;
+}
 __device__ __forceinline__ u32x2 lds_read_tr8_at(unsigned addr) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)addr);

@@ -227,6 +227,19 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #endif
     constexpr bool kSpread = FA_RP16_SPREAD != 0 && kWv == 4 && !kDma && !pair_tiles(D, X, kDma);
     constexpr int kLandLast = kSpread ? kLandSlot + 2 * kLoads - 1 : kLandSlot;   // the slot of the last landing write
+    // ... and the tile barrier is replaced by one flag word per wave behind the ring: a wave publishes "tile j+2 landed" (its
+    // iteration count) right behind its last landing write and looks at all four flags only in front of its first read of that
+    // tile, most of a step later -- LDS operations of a wave complete in order, so the flag follows the data and the reads
+    // follow the look.  A lone wave per SIMD that waits at s_barrier for the slowest of four idles its matrix pipe; here the
+    // waves may drift by most of a step.  (Ring reuse: a wave lands tile j+3 over tile j-1 only behind its look of iteration
+    // j+1, i.e. when every wave has landed tile j+2 -- 16 slots into the second step of iteration j, past its last read of
+    // tile j-1 in the first.)
+#ifndef FA_RP16_FLAGBAR
+#define FA_RP16_FLAGBAR 1
+#endif
+    constexpr bool kFlagBar = kSpread && FA_RP16_FLAGBAR != 0 && (FA_RP16_ABL & 24) == 0;
+    constexpr int kFlagCheck = (kNF - kAhead) * X + X - 2, kFlagRead = kFlagCheck - 8;   // the slot in front of the first read-ahead into the next step
+    static_assert(!kFlagBar || (kFlagRead > 2 * kLoads && kLandLast + 1 < kSlots), "flag slots");
     static_assert(kLandLast < kSlots && 2 * kLoads <= kSlots, "the landing fits the step");
     constexpr int kLdsAfterLand = [] {
         int n = 0;
@@ -467,6 +480,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                 else buf_store8(ro0, rb0 * D * 2u, u32x2{z[0], z[1]});
             }
         }
+    }
+    [[maybe_unused]] unsigned epoch = 0u, flag_seen = 0u;   // kFlagBar: iterations this wave has published (uniform; the same in every wave)
+    [[maybe_unused]] const unsigned flag_base = lds_addr(smem_all) + kRingSlots * kSlotBytes;
+    if constexpr (kFlagBar) {
+        if (tid < (unsigned)kW) lds_write4_at(flag_base + 4u * tid, 0u);
+        __syncthreads();
     }
     for (unsigned bid = first_bid; bid < nwg; bid = kScan ? scan_next() : bid + gridDim.x) {
 #ifdef FA_RP16_STAMPS   // lab: 100 MHz timestamps of the item's phases, written over O[first row of the item][0..7] (fp32 out only)
@@ -769,6 +788,19 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         sfor<kSlots>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kFlagBar) {
+                if constexpr (h == 0 && i == kFlagRead) flag_seen = lds_read4_at(flag_base + 4u * (lane & (unsigned)(kW - 1)));
+                if constexpr (h == 0 && i == kFlagCheck) {   // every wave has landed the tile the next fragment reads touch
+                    while (!__all((int)(flag_seen - epoch) >= 0)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        flag_seen = lds_read4_at(flag_base + 4u * (lane & (unsigned)(kW - 1)));
+                    }
+                }
+                if constexpr (h == 1 && i == kLandLast + 1) {   // this wave's chunks of tile j+2 are in LDS (in order behind them)
+                    ++epoch;
+                    lds_write4_at(flag_base + 4u * wave, epoch);
+                }
+            }
             if constexpr (kSpread && (FA_RP16_ABL & 8) == 0) {
                 if constexpr (h == 0 && i < 2 * kLoads && decltype(req_c)::value) {   // request chunk i of tile j+2
                     constexpr int p = i >> 1;
@@ -984,7 +1016,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         // immediates of the LDS instructions instead of one v_add per fragment read), -1 otherwise
         // req_c: request tile j+2 at the top (not in iteration 0 of the non-DMA path: the prologue already has it in flight)
         auto tile_barrier = [&]() __attribute__((always_inline)) {
-            if constexpr ((FA_RP16_ABL & 16) != 0) {
+            if constexpr ((FA_RP16_ABL & 16) != 0 || kFlagBar) {
             } else if constexpr (FA_RP16_RAWBAR != 0 && !kDma && kLdsAfterLand <= 15) {
                 // The barrier publishes this wave's ds_writes of the landed tile (first read at least one iteration later) and orders
                 // the ring's reuse; it does not need the fragment reads issued since (LDS operations of a wave complete in order: once
@@ -1341,7 +1373,8 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     constexpr int kW = kWv;
     constexpr int lds_bytes = kKeySplit * ((pair_tiles(D, X, kDma) && kKeySplit == 1) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring(s) of four (eight) [K tile][V tile] slots
     if (kKeySplit > 1 && N % (kBlockN * kKeySplit) != 0) return hipErrorInvalidValue;
-    constexpr int lds_extra = (FA_RP16_OLDS != 0 && kOutF32 && D == 64 && !pair_tiles(D, X, kDma) && kKeySplit == 1) ? kWv * 16 * 256 : 0;   // the output staging region
+    constexpr int lds_extra = ((FA_RP16_OLDS != 0 && kOutF32 && D == 64 && !pair_tiles(D, X, kDma) && kKeySplit == 1) ? kWv * 16 * 256 : 0)   // the output staging region
+                              + (kWv == 4 ? 64 : 0);   // one wave per SIMD: the waves' landing flags
     constexpr int kRows = 16 * X * kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
