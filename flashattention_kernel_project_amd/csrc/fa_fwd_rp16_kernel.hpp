@@ -237,9 +237,10 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #ifndef FA_RP16_FLAGBAR
 #define FA_RP16_FLAGBAR 1
 #endif
-    constexpr bool kFlagBar = kSpread && FA_RP16_FLAGBAR != 0 && (FA_RP16_ABL & 24) == 0;
-    constexpr int kFlagCheck = (kNF - kAhead) * X + X - 2, kFlagRead = kFlagCheck - 8;   // the slot in front of the first read-ahead into the next step
-    static_assert(!kFlagBar || (kFlagRead > 2 * kLoads && kLandLast + 1 < kSlots), "flag slots");
+    constexpr bool kFlagBar = (FA_RP16_FLAGBAR == 2 ? (!kDma && !pair_tiles(D, X, kDma) && kKeySplit == 1 && !kScan && FA_RP16_OLDS == 0) : (kSpread && FA_RP16_FLAGBAR != 0)) &&
+                              (FA_RP16_ABL & 24) == 0;
+    constexpr int kFlagCheck = (kNF - kAhead) * X + X - 2, kFlagRead = kFlagCheck >= 8 ? kFlagCheck - 8 : 0;   // the slot in front of the first read-ahead into the next step
+    static_assert(!kFlagBar || ((!kSpread || kFlagRead > 2 * kLoads) && kFlagRead >= 0 && kLandLast + 1 < kSlots), "flag slots");
     static_assert(kLandLast < kSlots && 2 * kLoads <= kSlots, "the landing fits the step");
     constexpr int kLdsAfterLand = [] {
         int n = 0;
@@ -1374,7 +1375,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
     constexpr int lds_bytes = kKeySplit * ((pair_tiles(D, X, kDma) && kKeySplit == 1) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring(s) of four (eight) [K tile][V tile] slots
     if (kKeySplit > 1 && N % (kBlockN * kKeySplit) != 0) return hipErrorInvalidValue;
     constexpr int lds_extra = ((FA_RP16_OLDS != 0 && kOutF32 && D == 64 && !pair_tiles(D, X, kDma) && kKeySplit == 1) ? kWv * 16 * 256 : 0)   // the output staging region
-                              + (kWv == 4 ? 64 : 0);   // one wave per SIMD: the waves' landing flags
+                              + 64;   // the waves' landing flags (kFlagBar)
     constexpr int kRows = 16 * X * kW;
     const int nqb = (N + kRows - 1) / kRows;
     const long long nwg = (long long)BH * nqb;
