@@ -156,6 +156,6 @@ FA_EXPORT const char* fa_selected_kernel(int B, int H, int N, int d, int in_dtyp
     return algo < 0 ? "" : fa::algo_kernel_name(algo, d);
 }
 
-FA_EXPORT const char* fa_mi355_version(void) { return "fa_mi355 0.3.0 gfx950"; }
+FA_EXPORT const char* fa_mi355_version(void) { return "fa_mi355 0.3.1 gfx950"; }
 
 }  // extern "C"
