@@ -144,6 +144,33 @@ def lint_function(name, lines):
     for i in marked:
         for pos, ws, text in inbound(lines, i, labels):
             bad.append((i, pos, ws, "(in front) " + text))
+    # third check: an LDS read into a source register of a marked instruction has been waited for (the compiler's wait-count
+    # pass does see asm operands; this only confirms it on the listing).  Per basic block: LDS operations return in
+    # order, s_waitcnt lgkmcnt(n) leaves the n youngest outstanding.
+    pending = []
+    for i, l in enumerate(lines):
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            pending = []   # (inside basic blocks only: what is outstanding at a join depends on the path taken)
+            continue
+        op, ops = operands(l)
+        if not op or op.endswith(":") or op.startswith("."):
+            continue
+        if op.startswith("ds_"):
+            pending.append((i, regs(ops[0]) if (op.startswith("ds_read") or "permute" in op or "swizzle" in op) and ops else set()))
+        elif op.startswith("s_load") or op.startswith("s_buffer_load"):
+            pending.append((i, set()))
+        elif op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", l)
+            if m:
+                n = int(m.group(1))
+                pending = pending[len(pending) - n:] if n > 0 else []
+        elif "fa_qk" in l and op.startswith("v_mfma"):
+            used = set()
+            for t in ops[1:]:
+                used |= regs(t)
+            for pi, dst in pending:
+                if dst & used:
+                    bad.append((i, pi, 0, "(LDS read not waited for) " + lines[pi].strip()))
     return len(marked), bad
 
 
