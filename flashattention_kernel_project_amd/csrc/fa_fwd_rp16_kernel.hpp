@@ -225,7 +225,8 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
 #ifndef FA_RP16_SPREAD
 #define FA_RP16_SPREAD 1
 #endif
-    constexpr bool kSpread = FA_RP16_SPREAD != 0 && kWv == 4 && !kDma && !pair_tiles(D, X, kDma);
+    constexpr bool kOneWave = kWv == 4 && kKeySplit == 1;   // one wave per SIMD
+    constexpr bool kSpread = FA_RP16_SPREAD != 0 && kOneWave && !kDma;
     constexpr int kLandLast = kSpread ? kLandSlot + 2 * kLoads - 1 : kLandSlot;   // the slot of the last landing write
     // ... and the tile barrier is replaced by one flag word per wave behind the ring: a wave publishes "tile j+2 landed" (its
     // iteration count) right behind its last landing write and looks at all four flags only in front of its first read of that
@@ -240,7 +241,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr bool kFlagBar = (FA_RP16_FLAGBAR == 2 ? (!kDma && !pair_tiles(D, X, kDma) && kKeySplit == 1 && !kScan && FA_RP16_OLDS == 0) : (kSpread && FA_RP16_FLAGBAR != 0)) &&
                               (FA_RP16_ABL & 24) == 0;
     constexpr int kFlagCheck = (kNF - kAhead) * X + X - 2, kFlagRead = kFlagCheck >= 8 ? kFlagCheck - 8 : 0;   // the slot in front of the first read-ahead into the next step
-    static_assert(!kFlagBar || ((!kSpread || kFlagRead > 2 * kLoads) && kFlagRead >= 0 && kLandLast + 1 < kSlots), "flag slots");
+    static_assert(!kFlagBar || (kFlagRead >= 0 && kFlagRead < kFlagCheck && kLandLast + 1 < kSlots), "flag slots");
     static_assert(kLandLast < kSlots && 2 * kLoads <= kSlots, "the landing fits the step");
     constexpr int kLdsAfterLand = [] {
         int n = 0;
@@ -251,11 +252,11 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     constexpr unsigned kRowB = D * 2;
     constexpr unsigned kTile = kBlockN * D * 2;
     constexpr unsigned kSlotBytes = 2 * kTile;      // [K tile][V tile]
-    constexpr bool kPair = pair_tiles(D, X, kDma) && kKeySplit == 1;   // (two rings of eight slots do not fit)
+    constexpr bool kPair = pair_tiles(D, X, kDma) && kKeySplit == 1 && kWv == 8;   // (two rings of eight slots do not fit; one-wave kernels land per slot and use flags)
     // one wave per SIMD: QK^T spelled out with the scores in architectural registers (Mx::mfma_v*).  Every vector read of a score
     // lies at least X P.V matrix instructions behind the instruction that wrote it (the units alternate QK^T and P.V fragments and a
     // step ends with a P.V fragment); the prologue, whose reference maximum reads unit 0 at once, waits explicitly (settle).
-    constexpr bool kAsmQK = FA_RP16_ASMQK != 0 && kWv == 4;
+    constexpr bool kAsmQK = FA_RP16_ASMQK != 0 && kWv == 4 && kKeySplit == 1;   // (the key-split kernel has four waves per GROUP: two per SIMD, builtins)
     constexpr unsigned kRingSlots = kPair ? 8u : 4u, kRingMask = kRingSlots - 1u;
     constexpr int kLook = kPair ? 3 : 2;            // a tile is landed this many tiles ahead of the iteration that starts with it
     extern __shared__ __attribute__((aligned(16))) char smem_all[];   // one ring of slots per key-split group
@@ -768,13 +769,14 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         [[maybe_unused]] unsigned kb_q[kKS], kb_n[kKS], vb_v = 0u, vb_n = 0u, land_k = 0u, land_v = 0u;
         [[maybe_unused]] __amdgpu_buffer_rsrc_t rk_t = rk, rv_t = rv;
         // (each base is formed behind the matrix instruction in front of its first read, not in a bunch at the top of the step)
-        static_assert(!kBases || kAhead == 2, "the fragments read ahead into the next step are K(0, 0) and V(0)");
+        static_assert(!kBases || kAhead <= 2 * kKS, "the fragments read ahead into the next step are of its first key block");
         auto form_base = [&](auto fc) {
             constexpr int f = decltype(fc)::value;   // fragment about to be read; f >= kNF: of the next step
             const unsigned smem_a = lds_addr(smem);
             if constexpr (f >= kNF) {
-                if constexpr (f == kNF) { kb_n[0] = smem_a + so_nq + k_rd[0]; asm volatile("" : "+v"(kb_n[0])); }
-                if constexpr (f == kNF + 1) { vb_n = smem_a + so_nv + v_rd4[0]; asm volatile("" : "+v"(vb_n)); }
+                constexpr int fp = f - kNF;
+                if constexpr ((fp & 1) == 0) { kb_n[fp >> 1] = smem_a + so_nq + k_rd[fp >> 1]; asm volatile("" : "+v"(kb_n[fp >> 1])); }
+                if constexpr (fp == 1) { vb_n = smem_a + so_nv + v_rd4[0]; asm volatile("" : "+v"(vb_n)); }
             } else if constexpr ((f & 1) == 0) {
                 constexpr int ks = (f >> 1) % kKS;
                 if constexpr (f - 2 * kKS < kAhead) {   // no earlier in-step fragment with this ks
@@ -832,7 +834,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
                     if constexpr (kBases) {
                         // chunk p of a thread lies 64 kW / kChunks rows below chunk 0 in both images (the K swizzle and the V block
                         // map repeat every 16 rows at D = 128): one address each, the rest in the immediate
-                        static_assert(!kBases || (D == 128 && (64 * kW) % G::kChunks == 0 && ((64 * kW) / G::kChunks) % 16 == 0), "chunk p = chunk 0 + p rows");
+                        static_assert(!kBases || ((64 * kW) % G::kChunks == 0 && ((64 * kW) / G::kChunks) % 16 == 0), "chunk p = chunk 0 + p rows, a multiple of 16 (both image maps repeat)");
                         constexpr unsigned kStepK = (64u * kW / G::kChunks) * kRowB, kStepV = (64u * kW / G::kChunks / 8u) * (unsigned)kDB * 256u;
                         if constexpr (i == kLandSlot) {
                             land_k = lds_addr(smem) + so_land + k_lds[0];
@@ -939,6 +941,12 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
         }
         __syncthreads();
         if constexpr (kMode == (kFold ? 0 : 1)) FA_STAMP(2);
+        if constexpr (kAsmQK) {   // Q' may have been finished by vector instructions just above: wait states the compiler would count for a builtin
+#pragma unroll
+            for (int x = 0; x < X; ++x)
+#pragma unroll
+                for (int ks = 0; ks < kKS; ++ks) asm volatile("s_nop 4" : "+v"(qf[x][ks]));
+        }
 #pragma unroll
         for (int kbl = 0; kbl < 2; ++kbl)   // S(unit 0)
 #pragma unroll
@@ -1372,7 +1380,7 @@ static hipError_t launch_rp16(const void* Q, const void* K, const void* V, void*
 {
     using namespace rp16;
     constexpr int kW = kWv;
-    constexpr int lds_bytes = kKeySplit * ((pair_tiles(D, X, kDma) && kKeySplit == 1) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring(s) of four (eight) [K tile][V tile] slots
+    constexpr int lds_bytes = kKeySplit * ((pair_tiles(D, X, kDma) && kKeySplit == 1 && kWv == 8) ? 8 : 4) * 2 * kBlockN * D * 2;   // ring(s) of four (eight) [K tile][V tile] slots
     if (kKeySplit > 1 && N % (kBlockN * kKeySplit) != 0) return hipErrorInvalidValue;
     constexpr int lds_extra = ((FA_RP16_OLDS != 0 && kOutF32 && D == 64 && !pair_tiles(D, X, kDma) && kKeySplit == 1) ? kWv * 16 * 256 : 0)   // the output staging region
                               + 64;   // the waves' landing flags (kFlagBar)
