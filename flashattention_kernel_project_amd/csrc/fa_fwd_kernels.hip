@@ -469,6 +469,8 @@ hipError_t w64x_dispatch(const void* Q, const void* K, const void* V, void* O,
                          hipStream_t stream);
 hipError_t rp16_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
                                 int BH, int N, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream);
+hipError_t rp16_causal_dispatch_1w(const void* Q, const void* K, const void* V, void* O,
+                                int BH, int N, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream);
 hipError_t rp16_dispatch(const void* Q, const void* K, const void* V, void* O,
                          int BH, int N, int D, float scale, int in_dtype, int out_dtype, int fold,
                          hipStream_t stream);
@@ -598,7 +600,7 @@ hipError_t forward_dispatch(const void* Q, const void* K, const void* V, void* O
     return hipErrorInvalidValue;
 }
 
-// Causal forward (not a reference entry point).  algo: 0 auto, 1 generic, 2 tiled, 13 w64.
+// Causal forward (not a reference entry point).  algo: 0 auto, 1 generic, 2 tiled, 13 w64, 24 the pipeline, 28 the pipeline with one wave per SIMD (d = 128).
 hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, void* O,
                                    int BH, int N, int D, float scale, int in_dtype, int out_dtype,
                                    int algo, hipStream_t stream)
@@ -606,7 +608,7 @@ hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, 
     if (!Q || !K || !V || !O) return hipErrorInvalidValue;
     if (BH <= 0 || N <= 0 || D <= 0 || D % 16 != 0 || D > kGenMaxD) return hipErrorInvalidValue;
     if ((unsigned long long)(N + kBlockM) * D * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
-    if (algo != 0 && algo != 1 && algo != 2 && algo != 6 && algo != 13 && algo != 24) return hipErrorInvalidValue;
+    if (algo != 0 && algo != 1 && algo != 2 && algo != 6 && algo != 13 && algo != 24 && algo != 28) return hipErrorInvalidValue;
     if (in_dtype != 0 && in_dtype != 1) return hipErrorInvalidValue;
     // algo 13: the 64-rows-per-wave kernel with the mask; measured 3-4 % SLOWER than the plain tiled kernel
     // under the mask (B8 H16 N4096 d64: 0.462 vs 0.443 ms; N8192 d128: 2.41 vs 2.36 ms), so AUTO stays tiled.
@@ -618,9 +620,15 @@ hipError_t forward_causal_dispatch(const void* Q, const void* K, const void* V, 
 #endif
     // the pipeline under the mask (fa_fwd_rp16.hip): B8 H16 N4096 d64 fp16 0.309 ms against 0.369 for the tiled kernel (bf16 0.349 /
     // 0.364), N8192 d128 2.00 against 2.29 ms -- AUTO wherever the grid gives every CU a workgroup, else the tiled kernel
+    const bool algo_was_auto = algo == 0;
     if (algo == 0 && (D == 64 || D == 128) && N > 256 &&
         (long long)BH * ((N + (D == 64 ? 511 : 255)) / (D == 64 ? 512 : 256)) >= device_cus())
         algo = 24;
+    // d = 128, long sequences on grids of four rounds or more: one wave per SIMD as in the plain forward (B8 H16 N8192 2.005 vs 2.063 ms,
+    // B1 H32 N16384 2.55 vs 2.68; N = 4096 loses 2 %; profiles/r03_d128_variants.txt)
+    if (algo_was_auto && algo == 24 && D == 128 && N >= 8192 && (long long)BH * ((N + 255) / 256) >= 4 * (long long)device_cus())
+        algo = 28;
+    if (algo == 28) return rp16_causal_dispatch_1w(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);   // (d = 128 only)
     if (algo == 24) return rp16_causal_dispatch(Q, K, V, O, BH, N, D, scale, in_dtype, out_dtype, stream);
     if (in_dtype == 0)
         return out_dtype == 0 ? dispatch_causal_d<F16, true>(Q, K, V, O, BH, N, D, scale, algo, stream)

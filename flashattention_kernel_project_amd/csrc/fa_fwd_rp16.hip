@@ -16,6 +16,7 @@ RP16_FAMILY_DECL(rp16_d128x1);
 RP16_FAMILY_DECL(rp16_d128x4w4); // d = 128, one wave per SIMD: four 64-row waves, 256-row workgroups, 512 registers per wave
 RP16_FAMILY_DECL(rp16_c_d64);    // causal
 RP16_FAMILY_DECL(rp16_c_d128);
+RP16_FAMILY_DECL(rp16_c_d128w4);  // causal, d = 128, one wave per SIMD
 #ifdef FA_EXPERIMENTS
 RP16_FAMILY_DECL(rp16_d64x4_dma);
 hipError_t rp16_set_pass_ids_d64(unsigned*);
@@ -23,6 +24,7 @@ hipError_t rp16_set_pass_ids_d64n(unsigned*);
 hipError_t rp16_set_pass_ids_d128(unsigned*);
 hipError_t rp16_set_pass_ids_c(unsigned*);
 hipError_t rp16_set_pass_ids_d128w(unsigned*);
+hipError_t rp16_set_pass_ids_cw(unsigned*);
 hipError_t rp16_set_pass_ids_d64ks(unsigned*);
 hipError_t rp16_set_pass_ids(unsigned* dev_ptr)
 {
@@ -31,6 +33,7 @@ hipError_t rp16_set_pass_ids(unsigned* dev_ptr)
     if (e == hipSuccess) e = rp16_set_pass_ids_d128(dev_ptr);
     if (e == hipSuccess) e = rp16_set_pass_ids_c(dev_ptr);
     if (e == hipSuccess) e = rp16_set_pass_ids_d128w(dev_ptr);
+    if (e == hipSuccess) e = rp16_set_pass_ids_cw(dev_ptr);
     if (e == hipSuccess) e = rp16_set_pass_ids_d64ks(dev_ptr);
     return e;
 }
@@ -84,6 +87,15 @@ hipError_t rp16_causal_dispatch(const void* Q, const void* K, const void* V, voi
     const bool fold = (scale == scale) && scale * kLog2e != 0.0f;
     return D == 64 ? rp16_c_d64(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, fold, stream)
                    : rp16_c_d128(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, fold, stream);
+}
+
+// ... with one wave per SIMD (d = 128 only)
+hipError_t rp16_causal_dispatch_1w(const void* Q, const void* K, const void* V, void* O,
+                                   int BH, int N, int D, float scale, int in_dtype, int out_dtype, hipStream_t stream)
+{
+    if (D != 128 || !rp16_shape_ok(N, D)) return hipErrorInvalidValue;
+    const bool fold = (scale == scale) && scale * kLog2e != 0.0f;
+    return rp16_c_d128w4(Q, K, V, O, BH, N, scale, in_dtype, out_dtype, fold, stream);
 }
 
 }  // namespace fa

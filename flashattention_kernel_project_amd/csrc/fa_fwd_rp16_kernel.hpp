@@ -200,7 +200,7 @@ void fa_fwd_rp16_kernel(const uint16_t* __restrict__ Qg, const uint16_t* __restr
     // full-width waves (64 rows at D = 64, 32 at D = 128): the running-max pass lives in the redo kernel (see kScan)
     constexpr bool kSplitTrack = !kScan && !kDma && 16 * X * (D / 64) >= 64;
     constexpr unsigned kMarker = 0x7FA5C0DEu;
-    constexpr bool kVSplit = FA_RP16_VSPLIT != 0 && !kCausal;   // (under the mask the pins cost the full-width kernels spills)
+    constexpr bool kVSplit = FA_RP16_VSPLIT != 0 && (!kCausal || (kWv == 4 && kKeySplit == 1));   // (under the mask the pins cost the two-wave full-width kernels spills)
     static_assert(!(kCvtK && kDma), "the DMA path cannot convert K on the way");
     static_assert(!kDma || D == 64, "the DMA piece maps are written for 128-byte rows");
     constexpr int kRows = 16 * X * kW;

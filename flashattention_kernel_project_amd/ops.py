@@ -68,7 +68,7 @@ def fa_forward(q, k, v, scale: float | None = None, out_dtype=None, algo: int = 
                out=None, stream=None, causal: bool = False):
     """Attention forward on [B,H,N,d] (or [BH,N,d]) fp16/bf16 device tensors.
     out_dtype: torch.float32 (the reference's output type, default) or the input dtype.
-    causal: query row i attends to keys 0..i (fa_forward_causal; algo AUTO/GENERIC/TILED only)."""
+    causal: query row i attends to keys 0..i (fa_forward_causal; algo AUTO / GENERIC / TILED / RP16_FOLD, RP16_FOLD_1W at d=128)."""
     import torch
     if q.dim() == 3:
         B, (H, N, d) = 1, q.shape

@@ -48,7 +48,7 @@ extern "C" {
 #define FA_ALGO_RP16_FOLD_KS2  29 /* RP16_FOLD, D = 64, 128-row workgroups: two groups of four 32-row waves, each on half the keys, merged through LDS
                                      (N % 128 == 0; other N run _QUARTER); AUTO for few heads and N >= 2048 */
 #define FA_ALGO_RP16_FOLD_1W   28 /* RP16_FOLD at D = 128 with ONE wave per SIMD: four 64-row waves per 256-row workgroup, 512 registers each,
-                                     every LDS fragment feeding four matrix instructions; AUTO at D = 128 from N = 8192 on grids of >= 4 rounds */
+                                     every LDS fragment feeding four matrix instructions; AUTO at D = 128 from N = 8192 on grids of >= 4 rounds; also accepted by fa_forward_causal (D = 128) */
 /* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
  * A/B kernels that AUTO never selects. */
 #define FA_ALGO_W64            13 /* round 1's default for bf16: 64 query rows per wave, phase-ordered stream on 32x32x16, packed fp32 */
@@ -86,8 +86,9 @@ int fa_forward_ex(const void* Q, const void* K, const void* V, void* O,
  * "next" row of SURVEY.md 8(f) (cf. the runtime-M tail masking of
  * flashattn_warp_spc/flashattn_streaming_16x16_mw_v12d.cu:100-135).  algo: FA_ALGO_AUTO,
  * FA_ALGO_GENERIC, FA_ALGO_TILED (256-row workgroups), 6 (the tiled kernel with 128-row workgroups, two
- * per CU) or FA_ALGO_RP16_FOLD (the pipeline under the mask; AUTO's choice whenever the grid gives every CU a
- * workgroup); the last three need D in {64,128}.  (FA_ALGO_W64 under the mask: experimental build only.) */
+ * per CU), FA_ALGO_RP16_FOLD (the pipeline under the mask; AUTO's choice whenever the grid gives every CU a
+ * workgroup) or FA_ALGO_RP16_FOLD_1W (the same with one wave per SIMD, D = 128 only; AUTO's choice there from N = 8192 on
+ * grids of >= 4 rounds); all but the first two need D in {64,128}.  (FA_ALGO_W64 under the mask: experimental build only.) */
 int fa_forward_causal(const void* Q, const void* K, const void* V, void* O,
                       int B, int H, int N, int d, float scale,
                       int in_dtype, int out_dtype, int algo, void* stream);

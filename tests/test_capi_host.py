@@ -126,8 +126,9 @@ def test_spelled_out_matrix_instructions_keep_their_wait_states():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_lint.py"),
-                        os.path.join(root, "flashattention_kernel_project_amd", "csrc", "fa_fwd_rp16_d128w.hip")],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert re.search(r"total: \d+ spelled-out matrix instructions, 0 hazards", r.stdout), r.stdout[-500:]
+    for tu in ("fa_fwd_rp16_d128w.hip", "fa_fwd_rp16_cw.hip"):   # the plain and the causal one-wave families
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_lint.py"),
+                            os.path.join(root, "flashattention_kernel_project_amd", "csrc", tu)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, tu + "\n" + r.stdout[-3000:] + r.stderr[-1000:]
+        assert re.search(r"total: \d+ spelled-out matrix instructions, 0 hazards", r.stdout), r.stdout[-500:]

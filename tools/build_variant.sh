@@ -8,7 +8,7 @@ src=$root/flashattention_kernel_project_amd/csrc
 out=$root/gpurun_variants; obj=$out/obj_$name
 mkdir -p "$obj"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -fvisibility=hidden -Wall -Wno-unused-function"
-SRCS="fa_fwd_kernels.hip fa_fwd_il.hip fa_fwd_rp16.hip fa_fwd_rp16_d64.hip fa_fwd_rp16_d64n.hip fa_fwd_rp16_d64ks.hip fa_fwd_rp16_d128.hip fa_fwd_rp16_d128w.hip fa_fwd_rp16_c.hip fa_fwd_split.hip fa_debug_stages.hip fa_streaming16.hip fa_capi.hip"
+SRCS="fa_fwd_kernels.hip fa_fwd_il.hip fa_fwd_rp16.hip fa_fwd_rp16_d64.hip fa_fwd_rp16_d64n.hip fa_fwd_rp16_d64ks.hip fa_fwd_rp16_d128.hip fa_fwd_rp16_d128w.hip fa_fwd_rp16_c.hip fa_fwd_rp16_cw.hip fa_fwd_split.hip fa_debug_stages.hip fa_streaming16.hip fa_capi.hip"
 pids=()
 for s in $SRCS; do
   # only fa_fwd_sk.hip and fa_capi.hip depend on the knobs in practice; the rest are reused from the product build

@@ -37,7 +37,7 @@ def main():
     exp = fa.lib().fa_mi355_has_experiments() == 1   # the A/B kernels exist only in libfa_mi355_exp.so (FA_MI355_LIB=...)
     plain = {64: (0, 1, 2, 5, 6, 23, 24, 24, 24, 26, 26, 27, 27, 29, 29) + ((13, 14, 16, 17, 18, 19, 20, 21, 22, 25) if exp else ()),
              128: (0, 1, 2, 23, 24, 24, 26, 26, 28, 28) + ((13, 14, 16, 21) if exp else ())}
-    caus = {64: (0, 1, 2, 6, 24, 24) + ((13,) if exp else ()), 128: (0, 1, 2, 6, 24, 24) + ((13,) if exp else ())}
+    caus = {64: (0, 1, 2, 6, 24, 24) + ((13,) if exp else ()), 128: (0, 1, 2, 6, 24, 24, 28, 28) + ((13,) if exp else ())}
     t0, cases, fails, worst = time.time(), 0, 0, 0.0
     next_note = t0 + 60.0
     while time.time() - t0 < args.seconds:

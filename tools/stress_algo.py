@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--causal", action="store_true")
     args = ap.parse_args()
     import torch
     import flashattention_kernel_project_amd as fa
@@ -39,11 +40,14 @@ def main():
         q, k, v = (torch.randn(bh, n, args.d, generator=g, device="cuda") for _ in range(3))
         q, k, v = (q * spread).to(dt), (k * spread).to(dt), v.to(dt)
         scale = 1.0 / args.d ** 0.5
-        want = torch.softmax(torch.einsum("bid,bjd->bij", q.float(), k.float()) * scale, dim=-1) @ v.float()
+        s_ = torch.einsum("bid,bjd->bij", q.float(), k.float()) * scale
+        if args.causal:
+            s_ = s_.masked_fill(~torch.ones(n, n, dtype=torch.bool, device="cuda").tril_(), float("-inf"))
+        want = torch.softmax(s_, dim=-1) @ v.float()
         tol = 1e-2 * (1.0 if dt == torch.float16 else 2.5) * (1.0 if spread < 2.0 else 2.0)
         first = None
         for rep in range(3):   # the same launch again: results must not depend on timing
-            got = fa.fa_forward(q, k, v, scale=scale, algo=args.algo)
+            got = fa.fa_forward(q, k, v, scale=scale, algo=args.algo, causal=args.causal)
             err = float((got - want).abs().max())
             worst = max(worst, err if err == err else float("inf"))
             if first is None:
@@ -54,7 +58,7 @@ def main():
                 print(f"FAIL bh={bh} n={n} dt={dt} spread={spread} rep={rep} err={err:.3e} tol={tol:.1e} repeatable={same}", flush=True)
                 break
         cases += 1
-    print(f"stress algo {args.algo} d={args.d} seed {args.seed}: {cases} cases x 3 launches, {fails} failures, worst max-abs {worst:.3e}, {time.time() - t0:.0f} s")
+    print(f"stress algo {args.algo}{' causal' if args.causal else ''} d={args.d} seed {args.seed}: {cases} cases x 3 launches, {fails} failures, worst max-abs {worst:.3e}, {time.time() - t0:.0f} s")
     return 1 if fails else 0
 
 
