@@ -490,7 +490,7 @@ hipError_t w64_causal_dispatch(const void* Q, const void* K, const void* V, void
 //     bf16 0.487 (24) / 0.502 (23) / 0.528 (21, fa_fwd_rp) / 0.533 (fa_fwd_w64);
 //   d = 64, smaller grids or N <= 256: the interleaved kernel with 256-row workgroups, or 128-row ones (two per CU);
 //   d = 128: the same pipeline with two 16-row blocks per wave (256-row workgroups), B8 H16 N8192: fp16 3.74 ms against 3.94
-//     for fa_fwd_w64x, bf16 3.63 against 3.84 for fa_fwd_w64; from N = 8192 on grids of four rounds or more, one wave per SIMD (28);
+//     for fa_fwd_w64x, bf16 3.63 against 3.84 for fa_fwd_w64; from N = 4096 with one wave per SIMD (28);
 //   anything else: the generic single-fragment kernel.
 // The CU count is read from the current device per call.
 int auto_algo(int BH, int N, int D, int in_dtype)
@@ -519,12 +519,12 @@ int auto_algo(int BH, int N, int D, int in_dtype)
     // fragment feeds two matrix instructions; B1 H16 N2048 0.0268 vs 0.0280 ms, B2 H8 N4096 0.0821 vs 0.0882 (profiles/
     // r03_cfg3_variants.txt); at N = 1024 it loses 2 %
     if (best == 27 && D == 64 && N >= 2048 && N % 128 == 0) best = 29;
-    // d = 128, long sequences on a grid of several rounds: the same 256-row workgroups as FOUR 64-row waves, one per SIMD with the
-    // whole register file (28): every LDS fragment feeds four matrix instructions instead of two (the two-wave kernel's fragment
-    // reads need the LDS's whole bandwidth).  Same device, interleaved (profiles/r03_d128_variants.txt): B8 H16 N8192 3.60 vs 3.69 ms,
-    // B1 H32 N16384 3.52 vs 3.62; at N = 4096 (B4 H16) and on one-round grids (B1 H8 N8192) they tie, shorter sequences lose 3-5 %
-    // (nothing hides the prologue of a lone wave)
-    if (best == 24 && D == 128 && N >= 8192 && (long long)BH * ((N + 255) / 256) >= 4 * cus) best = 28;
+    // d = 128 from N = 4096: the same 256-row workgroups as FOUR 64-row waves, one per SIMD with the whole register file (28): every LDS
+    // fragment feeds four matrix instructions instead of two (the two-wave kernel's fragment reads need the LDS's whole bandwidth).
+    // Same device, interleaved (profiles/r03_d128_variants.txt, last table): B8 H16 N8192 3.49 vs 3.72 ms, B1 H32 N16384 3.40 vs 3.61,
+    // B4 H16 N4096 0.500 vs 0.513, B1 H8 N8192 (one round) 0.250 vs 0.256; at N = 2048 they tie, N = 1024 loses 1-2 % (nothing hides the
+    // prologue of a lone wave)
+    if (best == 24 && D == 128 && N >= 4096) best = 28;
     return best;
 }
 

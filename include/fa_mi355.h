@@ -48,7 +48,7 @@ extern "C" {
 #define FA_ALGO_RP16_FOLD_KS2  29 /* RP16_FOLD, D = 64, 128-row workgroups: two groups of four 32-row waves, each on half the keys, merged through LDS
                                      (N % 128 == 0; other N run _QUARTER); AUTO for few heads and N >= 2048 */
 #define FA_ALGO_RP16_FOLD_1W   28 /* RP16_FOLD at D = 128 with ONE wave per SIMD: four 64-row waves per 256-row workgroup, 512 registers each,
-                                     every LDS fragment feeding four matrix instructions; AUTO at D = 128 from N = 8192 on grids of >= 4 rounds; also accepted by fa_forward_causal (D = 128) */
+                                     every LDS fragment feeding four matrix instructions; AUTO at D = 128 from N = 4096; also accepted by fa_forward_causal (D = 128; AUTO there from N = 8192 on grids of >= 4 rounds) */
 /* Only in the experimental build (`make experimental`, fa_mi355_has_experiments() == 1; hipErrorInvalidValue otherwise):
  * A/B kernels that AUTO never selects. */
 #define FA_ALGO_W64            13 /* round 1's default for bf16: 64 query rows per wave, phase-ordered stream on 32x32x16, packed fp32 */

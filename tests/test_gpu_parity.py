@@ -653,8 +653,8 @@ def test_auto_dispatch_boundaries(fa, oracle, torch_cuda, fmt):
         heads = sorted({0, bh // 2, bh - 1})
         want = oracle.forward(q[heads], k[heads], v[heads], accum=0, nthreads=16)
         _check(oracle, got[heads], want, fmt, f"AUTO boundary bh={bh} n={n} fmt={fmt} -> algo {sel}")
-    # d = 128: one wave per SIMD (28) from N = 8192 on grids of at least four rounds of 256-row workgroups
-    for (bh, n, want_algo) in [(cus // 8, 8192, 28), (cus // 8 - 1, 8192, 24), (cus // 4, 8192 - 64, 24), (cus // 16, 16384, 28), (cus, 4096, 24)]:
+    # d = 128: one wave per SIMD (28) from N = 4096 wherever the 256-row workgroups are chosen
+    for (bh, n, want_algo) in [(cus // 8, 8192, 28), (cus // 32, 8192, 28), (cus // 4, 4096, 28), (cus // 4, 4096 - 64, 24), (cus // 16, 16384, 28), (cus, 2048, 24)]:
         assert L.fa_selected_algo(bh, 1, n, 128, fmt) == want_algo, (bh, n)
 
 
